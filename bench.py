@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the vectorised Hex hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 11x11, 65 536 parallel envs per GPU,
+random policy.  One "step" = one SelfPlayEnv.step per env (agent ply +
+opponent reply + auto reset; SURVEY 8(d) unit W1), agent and opponent both
+uniform-legal, drawn on the device.  The timed region runs the K steps as
+launches of the device-resident self-play rollout kernel (k_hex<rollout1>,
+T steps per launch, every step's obs / mask / action / reward / done written
+to HBM); the host-stepped rate (one hexvec_step launch per step) is reported
+beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_GBPS = 6290.0
+
+
+def cpu_baseline(board, seconds=12.0):
+    """The oracle (a C port of the reference algorithm) on this host's cores, same workload."""
+    from oracle import hex_oracle as ho
+    cores = os.cpu_count() or 1
+    E = 4096
+    o = ho.OracleVec(board, E, seed=0, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
+    o.set_threads(cores)
+    t0 = time.perf_counter()
+    o.step_repeat(8)
+    dt = time.perf_counter() - t0
+    K = max(8, int(8 * seconds / max(dt, 1e-6)))
+    K = min(K, 200000)
+    t0 = time.perf_counter()
+    o.step_repeat(K)
+    dt = time.perf_counter() - t0
+    return {"value": E * K / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{E} envs x {K} self-play steps, {board}x{board}, oracle/hex_oracle.c "
+                      f"on {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--board", type=int, default=11)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--chunk", type=int, default=50, help="env steps per rollout launch")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-stepped", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hex_gym_env_amd as hx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    N, E, T = args.board, args.envs, max(1, min(args.chunk, args.steps))
+    C = N * N
+    env = hx.HexVecEnv(N, E, device=dev, encoding="B", seed=0, env_offset=rank * E)
+    out = dict(obs=torch.empty((T, E, C), dtype=torch.int8, device=dev),
+               legal=torch.empty((T, E, C), dtype=torch.uint8, device=dev),
+               actions=torch.empty((T, E), dtype=torch.int32, device=dev),
+               reward=torch.empty((T, E), dtype=torch.float32, device=dev),
+               done=torch.empty((T, E), dtype=torch.uint8, device=dev))
+
+    def run_steps(k):
+        """k env steps as rollout launches of <= T steps; returns the launch count"""
+        n = 0
+        while k > 0:
+            t = min(T, k)
+            env.rollout_selfplay(t, out)
+            k -= t
+            n += 1
+        return n
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run_steps(args.warmup)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()            # libhexvec launches on torch's current stream, as do these events
+    launches = run_steps(args.steps)
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1)        # HIP events around the timed launches
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * E * args.steps / dt
+
+    # the dominant kernel: bytes it must write per env step (obs + mask + action + reward + done)
+    bytes_per_step = 2 * C + 9
+    avg_launch_s = kernel_ms * 1e-3 / launches
+    steps_per_launch = args.steps / launches
+    achieved = E * steps_per_launch * bytes_per_step / avg_launch_s / 1e9
+
+    extra = {}
+    if not args.no_host_stepped:
+        ks = min(args.steps, 500)
+        for _ in range(20):
+            env.step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(ks):
+            env.step()
+        fence()
+        extra["host_stepped_env_steps_per_s"] = world * E * ks / (time.perf_counter() - t0)
+        extra["host_stepped_bytes_per_step"] = 3 * C + 9
+
+    # episode statistics: the only cross-GPU exchange (logging), one all-gather over RCCL
+    stats = env.episode_stats()
+    if world > 1:
+        gathered = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        stats = torch.stack(gathered).sum(0)
+    stats = stats.cpu().tolist()
+
+    if rank == 0:
+        line = {
+            "metric": "env-steps/sec (random policy, 11x11)" if N == 11
+                      else f"env-steps/sec (random policy, {N}x{N})",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{N}x{N} Hex, {E} envs/GPU, SelfPlayEnv.step with uniform-legal "
+                                   f"agent and opponent (device RNG), auto reset, "
+                                   f"{T} steps per rollout launch",
+                       "board_size": N, "envs_per_gpu": E, "global_envs": world * E,
+                       "steps_per_launch": T, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_hex<N,B,rollout1>", "bytes_per_env_step": bytes_per_step,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "frac_of_copy_ceiling": achieved / HBM_COPY_GBPS},
+            "episodes": {"sum_return": stats[0], "sum_len": stats[1], "n": stats[2],
+                         "agent_wins": stats[3]},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,189 @@
+"""HexVecEnv: tensor-native front end of libhexvec (one wavefront per board).
+
+All observations / masks / rewards / dones are torch tensors on the GPU; the
+calls enqueue on torch's current stream and never synchronise.  The semantics
+per env are the reference's:
+
+  self-play handle, encoding B  : SelfPlayEnv.step / reset  (minihex/SelfplayWrapper.py:69-89, :174-199)
+  self-play handle, encoding A  : hex-v0 HexEnv.step / reset (minihex/HexGame.py:206-295)
+  two-sided handle, encoding B  : HexEnv.step / reset        (minihex/HexSingleGame.py:208-263)
+  two-sided handle, encoding A  : HexGame.make_move          (minihex/HexGame.py:85-111)
+
+with VecEnv-style auto reset of finished envs (unless auto_reset=False).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+__all__ = ["HexVecEnv"]
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HexVecEnv:
+    def __init__(self, board_size=11, num_envs=1024, device=None, seed=0, encoding="B",
+                 two_sided=False, agent_player_num=None, auto_reset=True, first_player=0,
+                 env_offset=0):
+        if not (_lib.MIN_BOARD <= board_size <= _lib.MAX_BOARD):
+            raise ValueError(f"board_size must be in {_lib.MIN_BOARD}..{_lib.MAX_BOARD}")
+        if encoding not in ("A", "B"):
+            raise ValueError("encoding must be 'A' (hex-v0 / HexGame.py) or 'B' (HexSingleGame.py)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("HexVecEnv needs an MI355X: libhexvec has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HexVecEnv runs on the GPU only (device must be cuda:N)")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        flags = 0
+        if encoding == "B":
+            flags |= _lib.F_ENC_B
+            if agent_player_num is None:
+                flags |= _lib.F_AGENT_RANDOM        # SelfplayWrapper.py:72-73
+            elif agent_player_num == 1:
+                flags |= _lib.F_AGENT_WHITE
+            elif agent_player_num != 0:
+                raise ValueError("agent_player_num must be None, 0 or 1")
+        else:
+            if agent_player_num not in (None, 0):
+                raise NotImplementedError(
+                    "hex-v0 with player_color=WHITE is broken in the reference (board and "
+                    "regions desynchronise, HexGame.py:245-248); only the BLACK agent is supported")
+            if first_player == 1:
+                flags |= _lib.F_FIRST_WHITE
+        if two_sided:
+            flags |= _lib.F_TWO_SIDED
+        if not auto_reset:
+            flags |= _lib.F_NO_AUTO_RESET
+        self.board_size, self.num_envs, self.encoding = board_size, num_envs, encoding
+        self.two_sided, self.auto_reset, self.flags = two_sided, auto_reset, flags
+        self.cells = board_size * board_size
+        self._L = _lib.lib()
+        self._h = C.c_void_p()
+        _lib.check(self._L.hexvec_create(C.byref(self._h), board_size, num_envs, idx,
+                                         C.c_uint64(seed & (2 ** 64 - 1)), flags, env_offset))
+        E, Cc, dev = num_envs, self.cells, self.device
+        self.obs = torch.empty((E, board_size, board_size), dtype=torch.int8, device=dev)
+        self.legal = torch.empty((E, Cc), dtype=torch.uint8, device=dev)
+        self.reward = torch.empty(E, dtype=torch.float32, device=dev)
+        self.done = torch.empty(E, dtype=torch.uint8, device=dev)
+        self.winner = torch.empty(E, dtype=torch.int8, device=dev)
+
+    # ------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.hexvec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _i32(self, a, shape):
+        if a is None:
+            return None
+        a = torch.as_tensor(a, device=self.device)
+        if a.dtype != torch.int32:
+            a = a.to(torch.int32)
+        a = a.contiguous()
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+        return a
+
+    # ------------------------------------------------------------------
+    def reset(self, env_mask=None, opp_actions=None):
+        """reset() of the masked envs (all by default) -> (obs int8 [E,N,N], legal uint8 [E,N*N])."""
+        m = None
+        if env_mask is not None:
+            m = torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.num_envs,):
+                raise ValueError("env_mask must have shape [num_envs]")
+        o = self._i32(opp_actions, (self.num_envs,))
+        _lib.check(self._L.hexvec_reset(self._h, _p(m), _p(o), _p(self.obs), _p(self.legal),
+                                        self._stream()))
+        return self.obs, self.legal
+
+    def step(self, actions=None, opp_actions=None, terminal_obs=None):
+        """One env step per board -> (obs, reward, done, legal, winner).
+
+        actions None = uniform-legal agent drawn on the device (the random-policy
+        workload); opp_actions None = uniform-legal opponent.  The returned
+        tensors are the env's own output buffers (overwritten by the next call).
+        """
+        a = self._i32(actions, (self.num_envs,))
+        o = self._i32(opp_actions, (self.num_envs,))
+        if terminal_obs is not None and (terminal_obs.dtype != torch.int8
+                                         or terminal_obs.numel() != self.num_envs * self.cells):
+            raise ValueError("terminal_obs must be int8 [E, N, N]")
+        _lib.check(self._L.hexvec_step(self._h, _p(a), _p(o), _p(self.obs), _p(self.legal),
+                                       _p(self.reward), _p(self.done), _p(self.winner),
+                                       _p(terminal_obs), self._stream()))
+        return self.obs, self.reward, self.done, self.legal, self.winner
+
+    def apply_moves(self, actions):
+        """Literal plies (no reset) from actions [T,E] -> ret, done, r_black, legal, obs (after each ply)."""
+        a = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        if a.dim() != 2 or a.shape[1] != self.num_envs:
+            raise ValueError("actions must have shape [T, num_envs]")
+        T, E, Cc, dev = a.shape[0], self.num_envs, self.cells, self.device
+        ret = torch.empty((T, E), dtype=torch.int8, device=dev)
+        done = torch.empty((T, E), dtype=torch.uint8, device=dev)
+        rb = torch.empty((T, E), dtype=torch.int8, device=dev)
+        legal = torch.empty((T, E, Cc), dtype=torch.uint8, device=dev)
+        obs = torch.empty((T, E, Cc), dtype=torch.int8, device=dev)
+        _lib.check(self._L.hexvec_apply_moves(self._h, _p(a), T, _p(ret), _p(done), _p(rb),
+                                              _p(legal), _p(obs), self._stream()))
+        return ret, done, rb, legal, obs
+
+    def _rollout(self, fn, T, out):
+        E, Cc, dev = self.num_envs, self.cells, self.device
+        if out is None:
+            out = dict(
+                obs=torch.empty((T, E, Cc), dtype=torch.int8, device=dev),
+                legal=torch.empty((T, E, Cc), dtype=torch.uint8, device=dev),
+                actions=torch.empty((T, E), dtype=torch.int32, device=dev),
+                reward=torch.empty((T, E), dtype=torch.float32, device=dev),
+                done=torch.empty((T, E), dtype=torch.uint8, device=dev))
+        _lib.check(fn(self._h, T, _p(out.get("obs")), _p(out.get("legal")), _p(out.get("actions")),
+                      _p(out.get("reward")), _p(out.get("done")), self._stream()))
+        return out
+
+    def rollout_random(self, T, out=None):
+        """T plies per board, both sides uniform-legal, state in registers (two-sided handles)."""
+        return self._rollout(self._L.hexvec_rollout_random, T, out)
+
+    def rollout_selfplay(self, T, out=None):
+        """T whole env steps per board with RNG agent and RNG opponent (self-play handles)."""
+        return self._rollout(self._L.hexvec_rollout_selfplay, T, out)
+
+    def get_state(self):
+        E, P, dev = self.num_envs, (self.board_size + 2) ** 2, self.device
+        board = torch.empty((E, self.cells), dtype=torch.int8, device=dev)
+        labels = torch.empty((E, 2, P), dtype=torch.uint8, device=dev)
+        cur = torch.empty(E, dtype=torch.uint8, device=dev)
+        _lib.check(self._L.hexvec_get_state(self._h, _p(board), _p(labels), _p(cur), self._stream()))
+        return board, labels, cur
+
+    def episode_stats(self):
+        """float64 [4] on the device: sum_return, sum_len, n_episodes, n_agent_wins."""
+        out = torch.empty(4, dtype=torch.float64, device=self.device)
+        _lib.check(self._L.hexvec_episode_stats(self._h, _p(out), self._stream()))
+        return out
+
+    def agent_colours(self):
+        out = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.hexvec_agent_colours(self._h, _p(out), self._stream()))
+        return out
+
+    def last_kernel(self):
+        return self._L.hexvec_last_kernel().decode()

@@ -1,0 +1,141 @@
+/*
+ * hexvec.h -- C ABI of libhexvec: thousands of independent Hex games stepped in
+ * lockstep on one MI355X (gfx950), one wavefront per board.
+ *
+ * The reference (MBPrdctns/hex_gym_env) has NO native/FFI interface: its hot
+ * path sits behind plain Python classes.  Each entry point below therefore
+ * names the reference Python interface it replaces (paths under minihex/).
+ * The Python binding a maintainer adds is in INTEGRATION.md (ctypes).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative HEXVEC_E_* on failure;
+ *     text via hexvec_last_error() (thread-local).  Illegal GAME actions are
+ *     not errors: they produce the reference's result (ret 3, HexGame.py:91-92).
+ *   - all data pointers are DEVICE pointers owned by the caller (torch
+ *     tensors); the library owns only its internal state.  Optional outputs
+ *     may be NULL.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls enqueue and
+ *     never synchronise; one handle = one device = one caller thread at a time.
+ *   - layouts: obs int8 [E, N*N] row-major board exactly as the reference's
+ *     `simulator.board` (encoding A: BLACK 0 / WHITE 1 / EMPTY 2, absolute;
+ *     encoding B: -1 / 0 / +1 in the perspective of the player to move);
+ *     legal uint8 [E, N*N] (1 = empty); actions int32 [E]; reward float32 [E];
+ *     done uint8 [E]; winner/ret int8 [E]: -1 None, 0 BLACK, 1 WHITE, 3 illegal.
+ *   - board_size 2..14 (labels are one byte, a padded plane is one dword per
+ *     lane); larger boards are rejected with HEXVEC_E_ARG.
+ *
+ * Random numbers (only when the library picks an action): counter based,
+ *   key  = mix32(env_global * 0x9E3779B9 + seed_lo) ^ seed_hi
+ *   draw = mix32(key + ctr * 0x9E3779B9), ctr++ per draw, per env
+ *   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16
+ *   action = k-th empty cell (row-major, in the mover's view), k = mulhi32(draw, n_empty)
+ * so results do not depend on how envs are sharded over GPUs (env_offset).
+ */
+#ifndef HEXVEC_H
+#define HEXVEC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hexvec hexvec_t;
+
+#define HEXVEC_MIN_BOARD 2
+#define HEXVEC_MAX_BOARD 14
+
+/* error codes */
+#define HEXVEC_OK 0
+#define HEXVEC_E_ARG (-1)   /* bad size / null handle / bad flag combination */
+#define HEXVEC_E_HIP (-2)   /* a HIP runtime call failed                     */
+#define HEXVEC_E_NOGPU (-3) /* no gfx950 device / device_id out of range     */
+#define HEXVEC_E_MODE (-4)  /* entry point not valid for this handle's mode  */
+
+/* create flags */
+#define HEXVEC_F_ENC_B 0x1u         /* HexSingleGame.py encoding (else HexGame.py / hex-v0)      */
+#define HEXVEC_F_AGENT_WHITE 0x2u   /* enc B self-play: every agent plays WHITE                  */
+#define HEXVEC_F_AGENT_RANDOM 0x4u  /* enc B self-play: colour drawn once per env (SelfplayWrapper.py:72-73) */
+#define HEXVEC_F_NO_AUTO_RESET 0x8u /* finished envs are not restarted inside step               */
+#define HEXVEC_F_FIRST_WHITE 0x10u  /* enc A: constructor current_player_num = WHITE (HexGame.py:155) */
+#define HEXVEC_F_TWO_SIDED 0x20u    /* no in-env opponent: step = one ply of whoever is to move  */
+
+/* Allocates the internal state for num_envs boards on device_id and resets
+ * them (replaces HexEnv.__init__ HexGame.py:152-197 / HexSingleGame.py:163-196,
+ * SelfPlayEnv.__init__ SelfplayWrapper.py:39-67).  env_offset = global index of
+ * env 0 (multi-GPU sharding). */
+int hexvec_create(hexvec_t **out, int board_size, int num_envs, int device_id, uint64_t seed,
+                  uint32_t flags, uint32_t env_offset);
+int hexvec_destroy(hexvec_t *h);
+
+/* reset() of the envs whose env_mask byte is non-zero (NULL = all):
+ * HexEnv.reset HexGame.py:206-242 (enc A: the opponent opens when FIRST_WHITE),
+ * HexEnv.reset HexSingleGame.py:208-231 + SelfPlayEnv.reset SelfplayWrapper.py:69-89
+ * (enc B: the opponent opens when the agent is WHITE).  opp_actions (int32 [E],
+ * in the opponent's view) supplies those opening plies; NULL = uniform-legal RNG.
+ * obs/legal are written for ALL envs. */
+int hexvec_reset(hexvec_t *h, const uint8_t *env_mask, const int32_t *opp_actions, int8_t *obs,
+                 uint8_t *legal, void *stream);
+
+/* One env step per board.
+ * self-play handles: SelfPlayEnv.step SelfplayWrapper.py:174-199 (enc B) /
+ *   HexEnv.step HexGame.py:244-295 (enc A, agent BLACK): agent ply, opponent
+ *   reply if the game goes on, agent-indexed reward, then auto reset.
+ * TWO_SIDED handles: HexEnv.step HexSingleGame.py:233-263 (enc B) / one
+ *   HexGame.make_move HexGame.py:85-111 (enc A): one ply, reward of the mover.
+ * actions NULL = uniform-legal RNG agent; opp_actions NULL = RNG opponent.
+ * terminal_obs (int8 [E, N*N], optional) receives the final board of envs that
+ * finished in this call (untouched otherwise). */
+int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *opp_actions, int8_t *obs,
+                uint8_t *legal, float *reward, uint8_t *done, int8_t *winner,
+                int8_t *terminal_obs, void *stream);
+
+/* Parity entry (TWO_SIDED handles): T literal plies from actions [T, E], never
+ * resets, reproduces the reference on illegal plies and plies after the end.
+ * enc A: HexGame.make_move HexGame.py:85-111; enc B: HexEnv.step HexSingleGame.py:233-263.
+ * Outputs after each ply: ret [T,E], done [T,E] (simulator.done), r_black [T,E]
+ * (reward[0], enc B), legal [T,E,N*N], obs [T,E,N*N]. */
+int hexvec_apply_moves(hexvec_t *h, const int32_t *actions, int T, int8_t *ret_out,
+                       uint8_t *done_out, int8_t *r_black_out, uint8_t *legal_out,
+                       int8_t *obs_out, void *stream);
+
+/* Device-resident random rollout (TWO_SIDED handles): T plies per board with
+ * the state held in registers, both sides uniform-legal (minihex/__init__.py:8-12,
+ * SelfplayWrapper.py:16-22), auto reset.  Recorded per ply: the obs and mask
+ * the mover saw, its action, its reward, done.  All outputs optional. */
+int hexvec_rollout_random(hexvec_t *h, int T, int8_t *obs /* [T,E,N*N] */, uint8_t *legal,
+                          int32_t *actions /* [T,E] */, float *reward, uint8_t *done,
+                          void *stream);
+
+/* Self-play handles: T whole env steps per launch with an RNG agent and RNG
+ * opponent (the random-policy throughput workload).  Recorded per step: the
+ * agent's action, reward, done and the obs/mask returned by the step. */
+int hexvec_rollout_selfplay(hexvec_t *h, int T, int8_t *obs /* [T,E,N*N] */, uint8_t *legal,
+                            int32_t *actions /* [T,E] */, float *reward, uint8_t *done,
+                            void *stream);
+
+/* Internal state in the reference's own layout: board int8 [E,N*N]
+ * (simulator.board), labels uint8 [E,2,(N+2)^2] (simulator.regions), engine
+ * current_player_num uint8 [E]. */
+int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uint8_t *cur_player,
+                     void *stream);
+
+/* out4 (device, double[4]) = sum of episode returns, sum of episode lengths,
+ * episodes finished, episodes the agent (TWO_SIDED: BLACK) won -- since create. */
+int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream);
+
+/* agent colour per env, uint8 [E] (device) */
+int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream);
+
+int hexvec_board_size(const hexvec_t *h);
+int hexvec_num_envs(const hexvec_t *h);
+uint32_t hexvec_flags(const hexvec_t *h);
+
+/* name of the kernel the last call of this thread launched (for profiling) */
+const char *hexvec_last_kernel(void);
+const char *hexvec_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

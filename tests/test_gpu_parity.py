@@ -1,0 +1,364 @@
+"""GPU parity: libhexvec (HIP, through the C ABI) vs the golden fixtures generated
+from the reference and vs the CPU oracle on seeded inputs.  Bit-exact: this is
+integer / byte work, every comparison is array_equal."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import hex_oracle as ho  # noqa: E402  (the checker)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def hx():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (torch.cuda.is_available() is False)")
+    import hex_gym_env_amd
+    return hex_gym_env_amd
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _unpack(bits, n):
+    return np.unpackbits(bits, axis=-1)[..., :n * n]
+
+
+# ----------------------------------------------------------------------------
+# golden fixtures (reference outputs)
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("enc,fname", [("A", "engineA.npz"), ("B", "envB.npz")])
+def test_apply_moves_matches_reference_fixtures(hx, enc, fname):
+    d = np.load(os.path.join(GOLDEN, fname))
+    for n in d["sizes"]:
+        n = int(n)
+        if n > 14:
+            continue
+        G = int(d[f"N{n}_ngames"])
+        for first in ((0, 1) if enc == "A" else (0,)):
+            games = [g for g in range(G) if enc == "B" or int(d[f"N{n}_g{g}_first"]) == first]
+            T = max(len(d[f"N{n}_g{g}_actions"]) for g in games)
+            acts = np.full((T, len(games)), -1, np.int32)      # -1 = illegal ply: regions unchanged
+            for i, g in enumerate(games):
+                a = d[f"N{n}_g{g}_actions"]
+                acts[:len(a), i] = a
+            env = hx.HexVecEnv(n, len(games), encoding=enc, two_sided=True, auto_reset=False,
+                               first_player=first)
+            ret, done, rb, legal, obs = (_np(x) for x in env.apply_moves(acts))
+            _, labels, _ = env.get_state()
+            labels = _np(labels)
+            for i, g in enumerate(games):
+                k = f"N{n}_g{g}_"
+                L = len(d[k + "actions"])
+                assert np.array_equal(ret[:L, i], d[k + "ret"]), (k, "ret")
+                assert np.array_equal(done[:L, i], d[k + "done"]), (k, "done")
+                assert np.array_equal(legal[:L, i], _unpack(d[k + "mask"], n)), (k, "mask")
+                if enc == "A":
+                    assert np.array_equal(obs[:L, i], d[k + "board"]), (k, "board")
+                else:
+                    assert np.array_equal(obs[:L, i], d[k + "obs"]), (k, "obs")
+                    assert np.array_equal(rb[:L, i], d[k + "r_black"]), (k, "r_black")
+                assert np.array_equal(labels[i].reshape(2, n + 2, n + 2), d[k + "regions"]), (k, "regions")
+            env.close()
+
+
+def test_selfplay_step_matches_reference_fixtures(hx):
+    d = np.load(os.path.join(GOLDEN, "selfplay.npz"))
+    for n in d["sizes"]:
+        n = int(n)
+        for agent in (0, 1):
+            eps = [e for e in range(int(d[f"N{n}_neps"])) if int(d[f"N{n}_e{e}_agent"]) == agent]
+            E = len(eps)
+            env = hx.HexVecEnv(n, E, encoding="B", agent_player_num=agent, auto_reset=False)
+            ro = np.array([max(int(d[f"N{n}_e{e}_reset_opp_action"]), 0) for e in eps], np.int32)
+            obs, legal = env.reset(opp_actions=ro)
+            obs, legal = _np(obs).reshape(E, -1), _np(legal)
+            for i, e in enumerate(eps):
+                k = f"N{n}_e{e}_"
+                assert np.array_equal(obs[i], d[k + "reset_obs"]), k
+                assert np.array_equal(legal[i], _unpack(d[k + "reset_mask"], n)), k
+            T = max(len(d[f"N{n}_e{e}_actions"]) for e in eps)
+            for t in range(T):
+                a = np.zeros(E, np.int32)
+                oa = np.zeros(E, np.int32)
+                for i, e in enumerate(eps):
+                    k = f"N{n}_e{e}_"
+                    if t < len(d[k + "actions"]):
+                        a[i] = d[k + "actions"][t]
+                        oa[i] = max(int(d[k + "opp_actions"][t]), 0)
+                obs, rew, done, legal, win = env.step(a, oa)
+                obs, rew, done, legal = _np(obs).reshape(E, -1), _np(rew), _np(done), _np(legal)
+                for i, e in enumerate(eps):
+                    k = f"N{n}_e{e}_"
+                    if t < len(d[k + "actions"]):
+                        assert np.array_equal(obs[i], d[k + "obs"][t]), (k, t)
+                        assert rew[i] == d[k + "reward"][t], (k, t)
+                        assert done[i] == d[k + "done"][t], (k, t)
+                        assert np.array_equal(legal[i], _unpack(d[k + "mask"], n)[t]), (k, t)
+            env.close()
+
+
+def test_hexv0_step_matches_reference_fixtures(hx):
+    d = np.load(os.path.join(GOLDEN, "envA.npz"))
+    for n in d["sizes"]:
+        n = int(n)
+        for first in (0, 1):
+            eps = [e for e in range(int(d[f"N{n}_neps"])) if int(d[f"N{n}_e{e}_first"]) == first]
+            E = len(eps)
+            env = hx.HexVecEnv(n, E, encoding="A", auto_reset=False, first_player=first)
+            ro = np.array([max(int(d[f"N{n}_e{e}_reset_opp_action"]), 0) for e in eps], np.int32)
+            obs, legal = env.reset(opp_actions=ro)
+            obs, legal = _np(obs).reshape(E, -1), _np(legal)
+            for i, e in enumerate(eps):
+                k = f"N{n}_e{e}_"
+                assert np.array_equal(obs[i], d[k + "reset_obs"]), k
+                assert np.array_equal(legal[i], _unpack(d[k + "reset_mask"], n)), k
+            T = max(len(d[f"N{n}_e{e}_actions"]) for e in eps)
+            for t in range(T):
+                a = np.zeros(E, np.int32)
+                oa = np.zeros(E, np.int32)
+                for i, e in enumerate(eps):
+                    k = f"N{n}_e{e}_"
+                    if t < len(d[k + "actions"]):
+                        a[i] = d[k + "actions"][t]
+                        oa[i] = max(int(d[k + "opp_actions"][t]), 0)
+                obs, rew, done, legal, win = env.step(a, oa)
+                obs, rew, done, legal, win = (_np(obs).reshape(E, -1), _np(rew), _np(done),
+                                              _np(legal), _np(win))
+                for i, e in enumerate(eps):
+                    k = f"N{n}_e{e}_"
+                    if t < len(d[k + "actions"]):
+                        assert np.array_equal(obs[i], d[k + "obs"][t]), (k, t)
+                        assert rew[i] == d[k + "reward"][t], (k, t)
+                        assert done[i] == d[k + "done"][t], (k, t)
+                        assert win[i] == d[k + "winner"][t], (k, t)
+                        assert np.array_equal(legal[i], _unpack(d[k + "mask"], n)[t]), (k, t)
+            env.close()
+
+
+# ----------------------------------------------------------------------------
+# oracle on seeded inputs
+# ----------------------------------------------------------------------------
+def _flags(enc, two_sided, agent, auto_reset, first):
+    f = 0
+    if enc == "B":
+        f |= ho.F_ENC_B
+        if agent is None:
+            f |= ho.F_AGENT_RANDOM
+        elif agent == 1:
+            f |= ho.F_AGENT_WHITE
+    elif first == 1:
+        f |= ho.F_FIRST_WHITE
+    if two_sided:
+        f |= ho.F_TWO_SIDED
+    if not auto_reset:
+        f |= ho.F_NO_AUTO_RESET
+    return f
+
+
+def _pair(hx, n, E, enc, two_sided=False, agent=None, auto_reset=True, first=0, seed=7, off=0):
+    g = hx.HexVecEnv(n, E, encoding=enc, two_sided=two_sided, agent_player_num=agent,
+                     auto_reset=auto_reset, first_player=first, seed=seed, env_offset=off)
+    o = ho.OracleVec(n, E, seed=seed, flags=_flags(enc, two_sided, agent, auto_reset, first),
+                     env_offset=off)
+    return g, o
+
+
+def _same_state(g, o):
+    gb, gl, gc = (_np(x) for x in g.get_state())
+    ob, ol, oc = o.get_state()
+    assert np.array_equal(gb, ob), "board"
+    assert np.array_equal(gl, ol), "labels"
+    assert np.array_equal(gc, oc), "cur"
+    assert np.array_equal(_np(g.episode_stats()), o.episode_stats()), "episode stats"
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 7, 8, 9, 11, 12, 13, 14])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_apply_moves_random_cells_vs_oracle(hx, n, enc):
+    """uniformly random cells: many illegal plies, plies after the end, full boards."""
+    E, T = 96, 3 * n * n + 5
+    rng = np.random.default_rng(100 * n + (enc == "B"))
+    acts = rng.integers(0, n * n, size=(T, E)).astype(np.int32)
+    g, o = _pair(hx, n, E, enc, two_sided=True, auto_reset=False, first=n % 2 if enc == "A" else 0)
+    gr = [_np(x) for x in g.apply_moves(acts)]
+    orr = o.apply_moves(acts)
+    for name, a, b in zip(("ret", "done", "r_black", "legal", "obs"), gr, orr):
+        assert np.array_equal(a, b), name
+    _same_state(g, o)
+
+
+@pytest.mark.parametrize("n", [3, 5, 7, 11, 13])
+@pytest.mark.parametrize("enc,agent,first", [("B", None, 0), ("B", 0, 0), ("B", 1, 0),
+                                             ("A", None, 0), ("A", None, 1)])
+def test_selfplay_rng_steps_vs_oracle(hx, n, enc, agent, first):
+    """W1: RNG agent + RNG opponent + auto reset, many episodes."""
+    E, K = 64, 6 * n
+    g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=1234 + n)
+    if enc == "B":
+        assert np.array_equal(_np(g.agent_colours()), o.agent_colours())
+    tob = torch.zeros((E, n, n), dtype=torch.int8, device="cuda")
+    for k in range(K):
+        obs, rew, done, legal, win = g.step(terminal_obs=tob)
+        oo, ol, orw, od, ow, otob = o.step(want_terminal=True)
+        assert np.array_equal(_np(obs).reshape(E, -1), oo), k
+        assert np.array_equal(_np(legal), ol), k
+        assert np.array_equal(_np(rew), orw), k
+        assert np.array_equal(_np(done), od), k
+        assert np.array_equal(_np(win), ow), k
+        m = od.astype(bool)
+        assert np.array_equal(_np(tob).reshape(E, -1)[m], otob[m]), k
+    assert o.episode_stats()[2] >= E // 2    # many finished episodes (incl. auto resets)
+    _same_state(g, o)
+
+
+@pytest.mark.parametrize("n", [4, 7, 11])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_selfplay_external_actions_vs_oracle(hx, n, enc):
+    """external agent actions (random cells, some illegal) + RNG opponent."""
+    E, K = 64, 5 * n
+    rng = np.random.default_rng(n)
+    g, o = _pair(hx, n, E, enc, agent=None, seed=99)
+    for k in range(K):
+        a = rng.integers(0, n * n, size=E).astype(np.int32)
+        obs, rew, done, legal, win = g.step(a)
+        oo, ol, orw, od, ow = o.step(a)
+        assert np.array_equal(_np(obs).reshape(E, -1), oo), k
+        assert np.array_equal(_np(legal), ol), k
+        assert np.array_equal(_np(rew), orw), k
+        assert np.array_equal(_np(done), od), k
+        assert np.array_equal(_np(win), ow), k
+    _same_state(g, o)
+
+
+@pytest.mark.parametrize("n", [3, 6, 11, 14])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_two_sided_steps_and_masked_reset_vs_oracle(hx, n, enc):
+    E, K = 64, 4 * n
+    rng = np.random.default_rng(n + 50)
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=5, first=1 if enc == "A" else 0)
+    for k in range(K):
+        a = rng.integers(0, n * n, size=E).astype(np.int32) if k % 3 else None
+        obs, rew, done, legal, win = g.step(a)
+        oo, ol, orw, od, ow = o.step(a)
+        assert np.array_equal(_np(obs).reshape(E, -1), oo), k
+        assert np.array_equal(_np(legal), ol), k
+        assert np.array_equal(_np(rew), orw), k
+        assert np.array_equal(_np(done), od), k
+        assert np.array_equal(_np(win), ow), k
+        if k % 7 == 3:
+            m = (rng.random(E) < 0.3).astype(np.uint8)
+            gobs, glegal = g.reset(env_mask=m)
+            oobs, olegal = o.reset(env_mask=m)
+            assert np.array_equal(_np(gobs).reshape(E, -1), oobs)
+            assert np.array_equal(_np(glegal), olegal)
+    _same_state(g, o)
+
+
+@pytest.mark.parametrize("n", [2, 5, 8, 11, 13, 14])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_rollout_random_vs_oracle(hx, n, enc):
+    """W2: device-resident rollout, every ply recorded, vs the oracle's loop."""
+    E, T = 80, 2 * n * n + 7
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=2024)
+    out = g.rollout_random(T)
+    oobs, olegal, oact, orew, odone = o.rollout(T)
+    assert np.array_equal(_np(out["obs"]), oobs)
+    assert np.array_equal(_np(out["legal"]), olegal)
+    assert np.array_equal(_np(out["actions"]), oact)
+    assert np.array_equal(_np(out["reward"]), orew)
+    assert np.array_equal(_np(out["done"]), odone)
+    _same_state(g, o)
+    # a second launch continues from the stored state
+    out = g.rollout_random(9)
+    o2 = o.rollout(9)
+    assert np.array_equal(_np(out["obs"]), o2[0])
+    assert np.array_equal(_np(out["done"]), o2[4])
+    _same_state(g, o)
+
+
+@pytest.mark.parametrize("n", [5, 11])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_rollout_selfplay_vs_oracle(hx, n, enc):
+    E, T = 64, 4 * n
+    g, o = _pair(hx, n, E, enc, agent=None, seed=31)
+    out = g.rollout_selfplay(T)
+    for t in range(T):
+        oo, ol, orw, od, ow = o.step()
+        assert np.array_equal(_np(out["obs"][t]), oo), t
+        assert np.array_equal(_np(out["legal"][t]), ol), t
+        assert np.array_equal(_np(out["reward"][t]), orw), t
+        assert np.array_equal(_np(out["done"][t]), od), t
+    _same_state(g, o)
+
+
+# ----------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[1]: 11x11, 65 536 envs)
+# ----------------------------------------------------------------------------
+def test_full_size_properties(hx):
+    n, E, T = 11, 65536, 32
+    g = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=3)
+    out = g.rollout_random(T)
+    obs, legal, act, rew, done = (out[k] for k in ("obs", "legal", "actions", "reward", "done"))
+    # mask == empties of the obs it was recorded with
+    assert torch.equal(legal, (obs == 0).to(torch.uint8))
+    # the recorded action is always a legal cell
+    assert bool(torch.gather(legal, 2, act.long().unsqueeze(-1)).all())
+    # a mover's reward is +1 exactly on the plies that end a game (no draws in Hex)
+    assert torch.equal(rew, done.float())
+    # stones on the board before ply t == plies since the last reset
+    stones = (obs != 0).sum(-1)
+    since = torch.zeros(E, dtype=torch.long, device="cuda")
+    for t in range(T):
+        assert torch.equal(stones[t], since)
+        since = torch.where(done[t].bool(), torch.zeros_like(since), since + 1)
+    # equal stone counts for both colours up to one
+    diff = (obs == -1).sum(-1) - (obs == 1).sum(-1)
+    assert int(diff.abs().max()) <= 1
+    st = _np(g.episode_stats())
+    assert st[2] == float(done.sum())
+    # sharding invariance: the upper half as its own shard (multi-GPU layout)
+    h = hx.HexVecEnv(n, E // 2, encoding="B", two_sided=True, seed=3, env_offset=E // 2)
+    out2 = h.rollout_random(T)
+    assert torch.equal(out2["obs"], obs[:, E // 2:])
+    assert torch.equal(out2["actions"], act[:, E // 2:])
+    # mean random game length (SURVEY: 107.4 plies at 11x11)
+    g2 = hx.HexVecEnv(n, 4096, encoding="B", two_sided=True, seed=11)
+    g2.rollout_random(600, out={})
+    s = _np(g2.episode_stats())
+    assert 100.0 < s[1] / s[2] < 115.0
+
+
+def test_selfplay_full_size_step_properties(hx):
+    n, E = 11, 65536
+    g = hx.HexVecEnv(n, E, encoding="B", seed=9)
+    col = g.agent_colours()
+    assert 0.45 < float(col.float().mean()) < 0.55
+    tot_done = 0
+    for k in range(80):
+        obs, rew, done, legal, win = g.step()
+        assert torch.equal(legal, (obs.reshape(E, -1) == 0).to(torch.uint8))
+        assert bool(((rew != 0) <= done.bool()).all())
+        tot_done += int(done.sum())
+    st = _np(g.episode_stats())
+    assert st[2] == tot_done and tot_done > E
+    assert abs(st[0]) < 0.1 * st[2]        # random vs random: about even
+
+
+def test_errors_are_loud(hx):
+    with pytest.raises(ValueError):
+        hx.HexVecEnv(15, 4)
+    with pytest.raises(NotImplementedError):
+        hx.HexVecEnv(5, 4, encoding="A", agent_player_num=1)
+    e = hx.HexVecEnv(5, 4, encoding="B")
+    with pytest.raises(RuntimeError):
+        e.rollout_random(4)              # needs a two-sided handle
+    with pytest.raises(ValueError):
+        e.step(np.zeros(3, np.int32))
