@@ -19,6 +19,7 @@ F_AGENT_RANDOM = 0x4
 F_NO_AUTO_RESET = 0x8
 F_FIRST_WHITE = 0x10
 F_TWO_SIDED = 0x20
+F_EXACT_LABELS = 0x40
 
 MIN_BOARD, MAX_BOARD = 2, 14
 

@@ -56,6 +56,7 @@ constexpr int STAT_WORDS = 4; // per env: episode sums, touched at episode end
 enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4 };
 
 struct KArgs {
+    unsigned char *fast; // lane-per-board state (fast handles)
     u32 *planes;
     u32 *hot;
     int *stats;
@@ -516,6 +517,10 @@ __global__ __launch_bounds__(64 * WPB) void k_hex(KArgs a)
     }
 }
 
+} // namespace hv
+#include "hexvec_lpb.h"
+namespace hv {
+
 // ---- cold kernels: state in the reference's own layout, statistics ----
 __global__ void k_get_state(const u32 *planes, const u32 *hot, int E, int N, int enc,
                             signed char *board, unsigned char *labels, unsigned char *cur)
@@ -581,6 +586,8 @@ struct hexvec {
     hv::u32 *planes;
     hv::u32 *hot;
     int *stats;
+    bool fast_mode;      // lane-per-board kernels + fast state (auto-reset handles)
+    unsigned char *fast;
 };
 
 static thread_local char g_err[512] = "";
@@ -633,10 +640,81 @@ static hipError_t launch(int N, int enc, int mode, const KArgs &a, hipStream_t s
     }
 }
 
+// ---- lane-per-board dispatch ----
+template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
+{
+    const int blocks = (a.E + 63) / 64;
+    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE>), dim3(blocks), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+template <int N, int ENC> static hipError_t lpb_launch_mode(int mode, const KArgs &a, hipStream_t st)
+{
+    switch (mode) {
+    case M_ROLLOUT2: return lpb_launch1<N, ENC, M_ROLLOUT2>(a, st);
+    case M_STEP: return lpb_launch1<N, ENC, M_STEP>(a, st);
+    case M_ROLLOUT1: return lpb_launch1<N, ENC, M_ROLLOUT1>(a, st);
+    case M_RESET: return lpb_launch1<N, ENC, M_RESET>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+#define HV_LPB_SIZES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+static hipError_t lpb_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st)
+{
+    switch (N) {
+#define HV_CASE(n) case n: return enc ? lpb_launch_mode<n, 1>(mode, a, st) : lpb_launch_mode<n, 0>(mode, a, st);
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+static size_t lpb_block_bytes(int N, int enc)
+{
+    switch (N) {
+#define HV_CASE(n) case n: return enc ? lpb::FastState<n, 1>::BLOCK_BYTES : lpb::FastState<n, 0>::BLOCK_BYTES;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return 0;
+    }
+}
+static hipError_t lpb_get_state(const hexvec *h, signed char *board, unsigned char *cur, hipStream_t st)
+{
+    const int C = h->N * h->N;
+    const long long total = (long long)h->E * (C + 1);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
+    switch (h->N) {
+#define HV_CASE(n)                                                                                   \
+    case n:                                                                                          \
+        if (enc) hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 1>), g, b, 0, st, h->fast, h->E, board, cur); \
+        else hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 0>), g, b, 0, st, h->fast, h->E, board, cur);     \
+        break;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+static hipError_t lpb_stats(const hexvec *h, double *out4, unsigned char *agents, hipStream_t st)
+{
+    const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
+    switch (h->N) {
+#define HV_CASE(n)                                                                                           \
+    case n:                                                                                                  \
+        if (enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1>), dim3(1), dim3(256), 0, st, h->fast, h->E, out4, agents); \
+        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0>), dim3(1), dim3(256), 0, st, h->fast, h->E, out4, agents);     \
+        break;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 static KArgs base_args(const hexvec *h)
 {
     KArgs a;
     memset(&a, 0, sizeof(a));
+    a.fast = h->fast;
     a.planes = h->planes;
     a.hot = h->hot;
     a.stats = h->stats;
@@ -660,11 +738,27 @@ static const char *kname(int mode)
     }
 }
 
+static const char *lpb_kname(int mode)
+{
+    switch (mode) {
+    case M_ROLLOUT2: return "k_lpb<rollout2>";
+    case M_STEP: return "k_lpb<step>";
+    case M_ROLLOUT1: return "k_lpb<rollout1>";
+    default: return "k_lpb<reset>";
+    }
+}
+
 static int run(hexvec *h, int mode, const KArgs &a, void *stream)
 {
     HV_HIP(hipSetDevice(h->device));
-    g_kernel = kname(mode);
-    HV_HIP(launch(h->N, (h->flags & HEXVEC_F_ENC_B) ? 1 : 0, mode, a, (hipStream_t)stream));
+    const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
+    if (h->fast_mode) {
+        g_kernel = lpb_kname(mode);
+        HV_HIP(lpb_launch(h->N, enc, mode, a, (hipStream_t)stream));
+    } else {
+        g_kernel = kname(mode);
+        HV_HIP(launch(h->N, enc, mode, a, (hipStream_t)stream));
+    }
     return HEXVEC_OK;
 }
 
@@ -696,10 +790,21 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     h->planes = nullptr;
     h->hot = nullptr;
     h->stats = nullptr;
+    h->fast = nullptr;
+    // auto-reset handles never see a ply after the end of a game: they run on the
+    // lane-per-board kernels unless the caller wants the reference's label planes
+    h->fast_mode = !(flags & (HEXVEC_F_NO_AUTO_RESET | HEXVEC_F_EXACT_LABELS)) && board_size >= 4;
     const size_t E = (size_t)num_envs;
-    if (hipMalloc(&h->planes, E * hv::PLANE_WORDS * 4) != hipSuccess ||
-        hipMalloc(&h->hot, E * hv::HOT_WORDS * 4) != hipSuccess ||
-        hipMalloc(&h->stats, E * hv::STAT_WORDS * 4) != hipSuccess) {
+    bool ok;
+    if (h->fast_mode) {
+        const size_t bytes = (size_t)((num_envs + 63) / 64) * hv::lpb_block_bytes(board_size, (flags & HEXVEC_F_ENC_B) ? 1 : 0);
+        ok = hipMalloc(&h->fast, bytes) == hipSuccess;
+    } else {
+        ok = hipMalloc(&h->planes, E * hv::PLANE_WORDS * 4) == hipSuccess &&
+             hipMalloc(&h->hot, E * hv::HOT_WORDS * 4) == hipSuccess &&
+             hipMalloc(&h->stats, E * hv::STAT_WORDS * 4) == hipSuccess;
+    }
+    if (!ok) {
         hexvec_destroy(h);
         return fail(HEXVEC_E_HIP, "%s", "hipMalloc of the env state failed");
     }
@@ -723,6 +828,7 @@ extern "C" int hexvec_destroy(hexvec_t *h)
     if (h->planes) (void)hipFree(h->planes);
     if (h->hot) (void)hipFree(h->hot);
     if (h->stats) (void)hipFree(h->stats);
+    if (h->fast) (void)hipFree(h->fast);
     delete h;
     return HEXVEC_OK;
 }
@@ -766,6 +872,9 @@ extern "C" int hexvec_apply_moves(hexvec_t *h, const int32_t *actions, int T, in
     HV_HANDLE(h);
     if (!(h->flags & HEXVEC_F_TWO_SIDED))
         return fail(HEXVEC_E_MODE, "%s", "hexvec_apply_moves needs a HEXVEC_F_TWO_SIDED handle");
+    if (h->fast_mode)
+        return fail(HEXVEC_E_MODE, "%s",
+                    "hexvec_apply_moves needs HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS (literal plies)");
     if (!actions || T < 0) return fail(HEXVEC_E_ARG, "%s", "actions is NULL or T < 0");
     if (T == 0) return HEXVEC_OK;
     hv::KArgs a = hv::base_args(h);
@@ -825,6 +934,14 @@ extern "C" int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uin
 {
     HV_HANDLE(h);
     HV_HIP(hipSetDevice(h->device));
+    if (h->fast_mode) {
+        if (labels)
+            return fail(HEXVEC_E_MODE, "%s",
+                        "label planes exist only on HEXVEC_F_EXACT_LABELS / NO_AUTO_RESET handles");
+        g_kernel = "k_lpb_get_state";
+        HV_HIP(hv::lpb_get_state(h, (signed char *)board, cur_player, (hipStream_t)stream));
+        return HEXVEC_OK;
+    }
     const int C = h->N * h->N, P = (h->N + 2) * (h->N + 2);
     const long long total = (long long)h->E * (C + 2 * P + 1);
     const int bs = 256;
@@ -841,6 +958,11 @@ extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)
     HV_HANDLE(h);
     if (!out4) return fail(HEXVEC_E_ARG, "%s", "out4 is NULL");
     HV_HIP(hipSetDevice(h->device));
+    if (h->fast_mode) {
+        g_kernel = "k_lpb_stats";
+        HV_HIP(hv::lpb_stats(h, out4, nullptr, (hipStream_t)stream));
+        return HEXVEC_OK;
+    }
     g_kernel = "k_stats";
     hipLaunchKernelGGL(hv::k_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, h->stats, h->E, out4);
     HV_HIP(hipGetLastError());
@@ -852,6 +974,11 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
     HV_HANDLE(h);
     if (!out) return fail(HEXVEC_E_ARG, "%s", "out is NULL");
     HV_HIP(hipSetDevice(h->device));
+    if (h->fast_mode) {
+        g_kernel = "k_lpb_stats";
+        HV_HIP(hv::lpb_stats(h, nullptr, out, (hipStream_t)stream));
+        return HEXVEC_OK;
+    }
     g_kernel = "k_agents";
     hipLaunchKernelGGL(hv::k_agents, dim3((h->E + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        h->hot, h->E, out);

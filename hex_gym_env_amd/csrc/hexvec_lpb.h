@@ -1,0 +1,577 @@
+// hexvec_lpb.h -- lane-per-board ("LPB") kernels: the throughput path.
+//
+// Why a second kernel family: with one wavefront per board every index
+// computation of a ply is wave-uniform and lands on the CU's single scalar
+// ALU; rocprofv3 shows that kernel at 0.94 SALU instructions per CU-cycle
+// (profiles/r01) -- scalar-issue bound at 6 % of the HBM roofline.  Here ONE
+// LANE owns one board (64 boards per wavefront), so the same work is VALU at
+// 64 boards per instruction, and what has to be indexed per board lives in LDS:
+//
+//   UF[p][board][PS]  one byte per cell and colour p, in that colour's OWN
+//                     frame (BLACK: y*N+x, WHITE: x*N+y, so both connect
+//                     row 0 with row N-1 and the hex neighbourhood is the same
+//                     six offsets).  0 = no stone of p; 1..C = child, parent
+//                     index + 1; 0xFC|f = root, f bit0/bit1 = its group touches
+//                     row 0 / row N-1.  A new stone becomes the root of every
+//                     group it touches (6 neighbour reads, pointer chase, OR
+//                     of the root flags); the mover wins iff its root flags
+//                     become 3.  That is plain connectivity, which SURVEY 4
+//                     verified equals the reference's label merging
+//                     (HexGame.py:124-142 + :101-105).
+//   IMG[v][board][C]  the observation bytes themselves, packed exactly as the
+//                     [E, N*N] output rows: v=0 the BLACK-to-move view, v=1
+//                     (encoding B) the WHITE-to-move view -F^T
+//                     (HexSingleGame.py:265-271).  A ply writes one byte in
+//                     each.  Emitting obs + legal mask for 64 boards is a
+//                     wave-cooperative copy LDS -> HBM with 16-byte loads and
+//                     stores of whole contiguous spans (64*C bytes per view).
+//
+// Empty-cell bitboards (one per frame) stay in registers for the uniform
+// random policy (k-th set bit) and the legality test.  Scalars (action,
+// reward, done) are one coalesced store per wave.
+//
+// Scope: handles with auto reset.  Then no ply is ever applied after the end
+// of a game and an illegal action ends the episode at once, so the literal
+// quirks (q1/q2 of SURVEY 8a) cannot be observed; handles created with
+// HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS use the wave-per-board
+// kernels, which keep the reference's label planes bit for bit.
+#pragma once
+
+namespace hv {
+namespace lpb {
+
+template <int N> struct Geo {
+    static constexpr int C = N * N;
+    static constexpr int JW = (C + 31) / 32; // bitboard words
+    static constexpr int PS0 = (C + 2 + 3) / 4 * 4;
+    static constexpr int PS = ((PS0 / 4) % 2 == 0) ? PS0 + 4 : PS0; // odd dword stride: lanes spread over banks
+    static constexpr int DUMMY = C;     // always 0: stands in for off-board neighbours
+    static constexpr int TRASH = C + 1; // absorbs predicated-off writes
+    static constexpr int UF_BYTES = 2 * 64 * PS;
+    static constexpr int IMG_BYTES = 64 * C; // per view; multiple of 16
+    static constexpr int NIT = (4 * C + 63) / 64; // 16-byte vectors per view / 64 lanes
+};
+
+// per-lane registers persisted between launches: [REGW][64] words per block
+template <int N> struct Regs {
+    static constexpr int JW = Geo<N>::JW;
+    static constexpr int REGW = 2 * JW + 8;
+};
+
+template <int N, int ENC> struct Lpb {
+    using G = Geo<N>;
+    static constexpr bool B = ENC == 1;
+    static constexpr int NV = B ? 2 : 1;
+    static constexpr int C = G::C, JW = G::JW, PS = G::PS;
+    static constexpr int IMG = G::UF_BYTES; // byte offset of IMG[0] in LDS
+    static constexpr int LDS_BYTES = G::UF_BYTES + NV * G::IMG_BYTES;
+    static constexpr unsigned char EMPTY_BYTE = B ? 0 : 2;
+
+    struct LS {
+        u32 E0[JW], E1[JW]; // empty cells in F order / FT order
+        int cur;            // player to move (B: also the frame of the stored board)
+        int done;
+        int winner;
+        int n_empty;
+        int agent;
+        u32 ctr, key;
+        int ep_ret, ep_len;
+        int sr, sl, se, sw;
+    };
+
+    static __device__ __forceinline__ int transpose(int a)
+    {
+        const int y = a / N;
+        return (a - y * N) * N + y;
+    }
+    static __device__ __forceinline__ void clear_bit(u32 (&E)[JW], int idx)
+    {
+        const u32 bit = 1u << (idx & 31);
+        const int w = idx >> 5;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) E[j] &= ~(w == j ? bit : 0u);
+    }
+    static __device__ __forceinline__ bool test_bit(const u32 (&E)[JW], int idx)
+    {
+        const int w = idx >> 5;
+        u32 word = 0;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) word = w == j ? E[j] : word;
+        return (word >> (idx & 31)) & 1u;
+    }
+    static __device__ __forceinline__ void fill_bits(u32 (&E)[JW])
+    {
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int left = C - 32 * j;
+            E[j] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        }
+    }
+    // position of the k-th set bit (k < popcount), all per lane
+    static __device__ __forceinline__ int kth_set(const u32 (&E)[JW], u32 k)
+    {
+        u32 c = 0, word = 0, base = 0;
+        int widx = 0;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const u32 pc = (u32)__popc(E[j]);
+            const bool here = !found && k < c + pc;
+            word = here ? E[j] : word;
+            base = here ? c : base;
+            widx = here ? j : widx;
+            found = found || here;
+            c += pc;
+        }
+        k -= base;
+        int pos = 0;
+#pragma unroll
+        for (int sh = 16; sh >= 1; sh >>= 1) {
+            const u32 lowmask = (1u << sh) - 1u;
+            const u32 cl = (u32)__popc(word & lowmask);
+            const bool up = k >= cl;
+            k = up ? k - cl : k;
+            word = up ? word >> sh : word;
+            pos += up ? sh : 0;
+        }
+        return widx * 32 + pos;
+    }
+
+    static __device__ __forceinline__ u32 draw(LS &s)
+    {
+        const u32 r = mix32(s.key + s.ctr * 0x9E3779B9U);
+        s.ctr += 1;
+        return r;
+    }
+    // uniform-legal action in frame f's row-major order (SelfplayWrapper.py:16-22 shape)
+    static __device__ __forceinline__ int rng_action(LS &s, int f)
+    {
+        const u32 r = draw(s);
+        if (s.n_empty <= 0) return 0;
+        const u32 k = __umulhi(r, (u32)s.n_empty);
+        u32 Ef[JW];
+#pragma unroll
+        for (int j = 0; j < JW; ++j) Ef[j] = f ? s.E1[j] : s.E0[j];
+        return kth_set(Ef, k);
+    }
+
+    static __device__ __forceinline__ void fresh_regs(LS &s, int first)
+    {
+        fill_bits(s.E0);
+        fill_bits(s.E1);
+        s.cur = first;
+        s.done = 0;
+        s.n_empty = C;
+        s.ep_ret = 0;
+        s.ep_len = 0;
+    }
+
+    // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
+    // true iff p now connects its two edges (HexGame.py:98-105 via connectivity).
+    static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int lane)
+    {
+        clear_bit(s.E0, idx0);
+        clear_bit(s.E1, idx1);
+        s.n_empty -= 1;
+        if (B) {
+            lds[IMG + lane * C + idx0] = p ? 1 : 0xFF;                 // view 0:  F, BLACK -1 / WHITE +1
+            lds[IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;  // view 1: -F^T
+        } else {
+            lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
+        }
+        // union-find in p's own frame
+        unsigned char *uf = lds + (p * 64 + lane) * PS;
+        const int a = p ? idx1 : idx0;
+        const int y = a / N, x = a - y * N;
+        const bool up = y > 0, dn = y < N - 1, lf = x > 0, rt = x < N - 1;
+        int nb[6];
+        nb[0] = up ? a - N : G::DUMMY;
+        nb[1] = (up && rt) ? a - N + 1 : G::DUMMY;
+        nb[2] = lf ? a - 1 : G::DUMMY;
+        nb[3] = rt ? a + 1 : G::DUMMY;
+        nb[4] = (dn && lf) ? a + N - 1 : G::DUMMY;
+        nb[5] = dn ? a + N : G::DUMMY;
+        int ix[6];
+        u32 e[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ix[i] = nb[i];
+            e[i] = uf[ix[i]];
+        }
+        // follow child pointers to the roots (all six chains of all lanes together)
+        for (;;) {
+            bool any = false;
+            bool ch[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                ch[i] = (e[i] - 1u) < 0xFBu; // 1..0xFB: child
+                any = any || ch[i];
+            }
+            if (!__ballot(any)) break;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                ix[i] = ch[i] ? (int)e[i] - 1 : ix[i];
+                e[i] = uf[ix[i]];
+            }
+        }
+        u32 fl = (y == 0 ? 1u : 0u) | (y == N - 1 ? 2u : 0u);
+        const unsigned char child = (unsigned char)(a + 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool st = e[i] != 0u; // a root of colour p
+            fl |= st ? (e[i] & 3u) : 0u;
+            uf[st ? ix[i] : G::TRASH] = child; // old root -> child of the new stone
+            uf[st ? nb[i] : G::TRASH] = child; // and the neighbour itself (path compression)
+        }
+        uf[a] = (unsigned char)(0xFCu | fl);
+        return fl == 3u;
+    }
+
+    // wave-cooperative: wipe the LDS rows of the boards in `mask`
+    static __device__ __forceinline__ void clear_boards(unsigned char *lds, u64 mask, int lane)
+    {
+        while (mask) {
+            const int d = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                if (lane < PS / 4) reinterpret_cast<u32 *>(lds + (p * 64 + d) * PS)[lane] = 0u;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                for (int i = lane; i < C; i += 64) lds[IMG + v * G::IMG_BYTES + d * C + i] = EMPTY_BYTE;
+        }
+    }
+
+    // wave-cooperative: rows of the boards in `mask` -> dst[(board) * C ...] (terminal observations)
+    static __device__ __forceinline__ void copy_rows(const unsigned char *lds, u64 mask, u64 view1, signed char *dst, int lane)
+    {
+        while (mask) {
+            const int d = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int v = B ? (int)((view1 >> d) & 1) : 0;
+            for (int i = lane; i < C; i += 64)
+                dst[(size_t)d * C + i] = (signed char)lds[IMG + v * G::IMG_BYTES + d * C + i];
+        }
+    }
+
+    // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`
+    static __device__ __forceinline__ void emit(const unsigned char *lds, u64 view1, signed char *obs,
+                                                unsigned char *legal, int nlive, bool vec_ok, int lane)
+    {
+        if (!obs && !legal) return;
+        const int live_bytes = nlive * C;
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = (it * 64 + lane) * 16;
+            if (byte0 >= G::IMG_BYTES) continue;
+            uint4 o = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
+            if (B) {
+                const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+                const int b0 = byte0 / C;
+                const int s = C - (byte0 - b0 * C); // bytes [0,s) of this vector belong to board b0
+                const u32 ph = (u32)(view1 >> b0);
+                const u32 m0 = 0u - (ph & 1u), m1 = 0u - ((ph >> 1) & 1u);
+                u32 oo[4] = {o.x, o.y, o.z, o.w};
+                const u32 rr[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sh = (s - 4 * k) * 8;
+                    const u32 T = sh <= 0 ? 0xffffffffu : (sh >= 32 ? 0u : (0xffffffffu << sh)); // bytes >= s
+                    const u32 M = (m0 & ~T) | (m1 & T);                                           // bytes taken from view 1
+                    oo[k] = (rr[k] & M) | (oo[k] & ~M);
+                }
+                o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+            }
+            uint4 l;
+            if (B) { // values 0x00 / 0x01 / 0xFF: empty <=> bit 0 clear
+                l = make_uint4(~o.x & 0x01010101u, ~o.y & 0x01010101u, ~o.z & 0x01010101u, ~o.w & 0x01010101u);
+            } else { // values 0 / 1 / 2: empty <=> bit 1 set
+                l = make_uint4((o.x >> 1) & 0x01010101u, (o.y >> 1) & 0x01010101u, (o.z >> 1) & 0x01010101u,
+                               (o.w >> 1) & 0x01010101u);
+            }
+            if (vec_ok && byte0 + 16 <= live_bytes) {
+                if (obs) *reinterpret_cast<uint4 *>(obs + byte0) = o;
+                if (legal) *reinterpret_cast<uint4 *>(legal + byte0) = l;
+            } else if (byte0 < live_bytes) {
+                const u32 ow[4] = {o.x, o.y, o.z, o.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (byte0 + k < live_bytes) {
+                        if (obs) obs[byte0 + k] = (signed char)((ow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+                        if (legal) legal[byte0 + k] = (unsigned char)((lw[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+                    }
+            }
+        }
+    }
+};
+
+// fast state in HBM, per block of 64 boards: [LDS image][REGW x 64 words]
+template <int N, int ENC> struct FastState {
+    using L = Lpb<N, ENC>;
+    static constexpr int REGW = Regs<N>::REGW;
+    static constexpr size_t BLOCK_BYTES = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
+};
+
+template <int N, int ENC, int MODE>
+__global__ __launch_bounds__(64) void k_lpb(KArgs a)
+{
+    using L = Lpb<N, ENC>;
+    using G = Geo<N>;
+    using LS = typename L::LS;
+    constexpr bool B = ENC == 1;
+    constexpr int C = G::C, JW = G::JW;
+    constexpr int REGW = Regs<N>::REGW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES];
+
+    const int lane = (int)threadIdx.x;
+    const int nb = (int)gridDim.x, bi = (int)blockIdx.x;
+    const int blk = (nb & 7) == 0 ? (bi & 7) * (nb >> 3) + (bi >> 3) : bi; // contiguous env ranges per XCD
+    const int e0 = blk * 64;
+    const int env = e0 + lane;
+    const bool live = env < a.E;
+    const int nlive = min(64, a.E - e0);
+    unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC>::BLOCK_BYTES;
+    u32 *rblk = reinterpret_cast<u32 *>(sblk + L::LDS_BYTES);
+    const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
+    const bool selfplay = !two;
+    const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
+    const bool vec_ok = ((size_t)a.E * C) % 16 == 0;
+
+    LS s;
+    s.key = mix32(((u32)env + a.env_offset) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi;
+    if (MODE == M_RESET && a.init) {
+        for (int i = lane; i < L::LDS_BYTES / 16; i += 64) {
+            const bool img = i * 16 >= L::IMG;
+            const u32 f = img ? L::EMPTY_BYTE * 0x01010101u : 0u;
+            reinterpret_cast<uint4 *>(lds)[i] = make_uint4(f, f, f, f);
+        }
+        s.ctr = 0;
+        s.winner = -1;
+        s.agent = !B ? 0 : (a.flags & HEXVEC_F_AGENT_RANDOM) ? (int)(mix32(s.key ^ 0xA5A5A5A5U) & 1u)
+                  : (a.flags & HEXVEC_F_AGENT_WHITE) ? 1 : 0;
+        s.sr = s.sl = s.se = s.sw = 0;
+        L::fresh_regs(s, first);
+    } else {
+        for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
+            reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(sblk)[i];
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            s.E0[j] = rblk[j * 64 + lane];
+            s.E1[j] = rblk[(JW + j) * 64 + lane];
+        }
+        const u32 *r = rblk + 2 * JW * 64;
+        s.ctr = r[0 * 64 + lane];
+        s.ep_ret = (int)r[1 * 64 + lane];
+        s.ep_len = (int)r[2 * 64 + lane];
+        const u32 fl = r[3 * 64 + lane];
+        s.cur = fl & 1;
+        s.done = (fl >> 2) & 1;
+        s.agent = (fl >> 3) & 1;
+        s.winner = (int)((fl >> 4) & 7) - 1;
+        s.n_empty = (int)(fl >> 8) & 0xff;
+        s.sr = (int)r[4 * 64 + lane];
+        s.sl = (int)r[5 * 64 + lane];
+        s.se = (int)r[6 * 64 + lane];
+        s.sw = (int)r[7 * 64 + lane];
+    }
+
+    // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: FT order).
+    // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
+    auto ply = [&](int act, int fr) -> int {
+        const bool inb = (unsigned)act < (unsigned)C;
+        const int at = inb ? L::transpose(act) : 0;
+        const int idx0 = fr ? at : act, idx1 = fr ? act : at;
+        if (!inb || !L::test_bit(s.E0, idx0)) return 3;
+        const int p = s.cur;
+        const bool win = L::place(lds, s, idx0, idx1, p, lane);
+        int ret = -1;
+        if (win) {
+            s.done = 1;
+            ret = p;
+        } else if (B && s.n_empty <= 0) { // HexSingleGame.py:117-119
+            s.done = 1;
+        }
+        s.cur = p ^ 1;
+        return ret;
+    };
+    // env B HexEnv.step (HexSingleGame.py:233-263) on top of ply(); returns reward[0]
+    auto envb_step = [&](int act) -> int {
+        const int mover = s.cur;
+        const int w = ply(act, mover);
+        s.winner = w;
+        int r = 0;
+        if (w == 3) {
+            s.done = 1;
+            s.cur = mover ^ 1; // the env flips its player and view even then (:259-260)
+        } else if (w == mover) {
+            r = 1;
+        }
+        return mover == 0 ? r : -r;
+    };
+    // the opponent's reply in self-play handles; returns reward[0] (B) / nothing used (A)
+    auto reset_lane = [&]() {
+        L::fresh_regs(s, first);
+    };
+    auto opening = [&](const int *opp) { // the opponent opens (SelfplayWrapper.py:79-80 / HexGame.py:224-230)
+        if (B) {
+            const int oa = opp ? opp[env] : L::rng_action(s, s.cur);
+            envb_step(oa);
+        } else {
+            const int oa = opp ? opp[env] : L::rng_action(s, 1);
+            s.winner = ply(oa, 1);
+        }
+    };
+
+    const size_t E = (size_t)a.E;
+
+    if (MODE == M_RESET) {
+        const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
+        if (!a.init) L::clear_boards(lds, __ballot(sel), lane);
+        if (sel) {
+            reset_lane();
+            const bool opens = selfplay && (B ? s.agent != 0 : first != 0);
+            if (opens) opening(a.opp_actions);
+        }
+        L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+    } else {
+        for (int t = 0; t < a.T; ++t) {
+            const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
+            const size_t o = ob + (size_t)lane;
+            if (MODE == M_ROLLOUT2)
+                L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
+                        a.legal ? a.legal + ob * C : nullptr, nlive, vec_ok, lane);
+            int act = 0, rew = 0, won = 0;
+            if (live) {
+                // the mover's own frame in B; absolute (F) coordinates in A
+                act = (MODE == M_STEP && a.actions) ? a.actions[o] : L::rng_action(s, B ? s.cur : 0);
+                if (two) {
+                    if (B) {
+                        const int mover = s.cur;
+                        const int rb = envb_step(act);
+                        rew = mover == 0 ? rb : -rb;
+                        s.ep_ret += rb;
+                        won = s.done && s.winner == 0;
+                    } else {
+                        const int mover = s.cur;
+                        const int w = ply(act, 0);
+                        s.winner = w;
+                        if (w == 3) s.done = 1;
+                        rew = w == mover ? 1 : (w == 3 ? -100 : 0);
+                        s.ep_ret += w == 0 ? 1 : (w == 1 ? -1 : 0);
+                        won = s.done && w == 0;
+                    }
+                } else if (B) { // SelfPlayEnv.step (SelfplayWrapper.py:174-199)
+                    int rb = envb_step(act);
+                    if (!s.done) {
+                        const int oa = (MODE == M_STEP && a.opp_actions) ? a.opp_actions[o] : L::rng_action(s, s.cur);
+                        rb = envb_step(oa);
+                    }
+                    rew = s.agent == 0 ? rb : -rb;
+                    s.ep_ret += rew;
+                    won = s.done && rew > 0;
+                } else { // hex-v0 HexEnv.step (HexGame.py:244-295), agent BLACK
+                    s.winner = ply(act, 0);
+                    if (s.winner == 3) s.done = 1;
+                    if (!s.done) {
+                        const int oa = (MODE == M_STEP && a.opp_actions) ? a.opp_actions[o] : L::rng_action(s, 1);
+                        s.winner = ply(oa, 1);
+                    }
+                    rew = s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0));
+                    s.ep_ret += rew;
+                    won = s.done && rew > 0;
+                }
+                s.ep_len += 1;
+                if (a.reward) a.reward[o] = (float)rew;
+                if (a.done) a.done[o] = (unsigned char)s.done;
+                if (a.winner) a.winner[o] = (signed char)s.winner;
+                if (a.actions_out) a.actions_out[o] = act;
+            }
+            const bool dn = live && s.done;
+            const u64 dmask = __ballot(dn);
+            if (dmask) {
+                if (a.tobs) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, a.tobs + ob * C, lane);
+                L::clear_boards(lds, dmask, lane);
+                if (dn) {
+                    s.sr += s.ep_ret;
+                    s.sl += s.ep_len;
+                    s.se += 1;
+                    s.sw += won;
+                    reset_lane();
+                    const bool opens = selfplay && (B ? s.agent != 0 : first != 0);
+                    if (opens) opening(nullptr);
+                }
+            }
+            if (MODE != M_ROLLOUT2)
+                L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
+                        a.legal ? a.legal + ob * C : nullptr, nlive, vec_ok, lane);
+        }
+    }
+
+    // state back to HBM
+    for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
+        reinterpret_cast<uint4 *>(sblk)[i] = reinterpret_cast<const uint4 *>(lds)[i];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        rblk[j * 64 + lane] = s.E0[j];
+        rblk[(JW + j) * 64 + lane] = s.E1[j];
+    }
+    u32 *r = rblk + 2 * JW * 64;
+    r[0 * 64 + lane] = s.ctr;
+    r[1 * 64 + lane] = (u32)s.ep_ret;
+    r[2 * 64 + lane] = (u32)s.ep_len;
+    r[3 * 64 + lane] = (u32)s.cur | ((u32)s.done << 2) | ((u32)s.agent << 3) | ((u32)(s.winner + 1) << 4) |
+                       ((u32)(s.n_empty & 0xff) << 8);
+    r[4 * 64 + lane] = (u32)s.sr;
+    r[5 * 64 + lane] = (u32)s.sl;
+    r[6 * 64 + lane] = (u32)s.se;
+    r[7 * 64 + lane] = (u32)s.sw;
+}
+
+// ---- cold kernels on the fast state ----
+template <int N, int ENC>
+__global__ void k_lpb_get_state(const unsigned char *fast, int E, signed char *board, unsigned char *cur)
+{
+    using L = Lpb<N, ENC>;
+    constexpr int C = Geo<N>::C;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)E * (C + 1)) return;
+    const int env = (int)(gid / (C + 1)), r = (int)(gid - (long long)env * (C + 1));
+    const int blk = env >> 6, lane = env & 63;
+    const unsigned char *sblk = fast + (size_t)blk * FastState<N, ENC>::BLOCK_BYTES;
+    const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N>::JW * 64;
+    const int c = (int)(regs[3 * 64 + lane] & 1u);
+    if (r < C) {
+        if (board) {
+            const int v = (ENC == 1 && c) ? 1 : 0;
+            board[(size_t)env * C + r] = (signed char)sblk[L::IMG + v * Geo<N>::IMG_BYTES + lane * C + r];
+        }
+    } else if (cur) {
+        cur[env] = (unsigned char)c;
+    }
+}
+
+template <int N, int ENC>
+__global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsigned char *agents)
+{
+    using L = Lpb<N, ENC>;
+    __shared__ double sh[4][256];
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < E; i += blockDim.x) {
+        const unsigned char *sblk = fast + (size_t)(i >> 6) * FastState<N, ENC>::BLOCK_BYTES;
+        const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N>::JW * 64;
+        for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i & 63)];
+        if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i & 63)] >> 3) & 1u);
+    }
+    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (out4 && threadIdx.x < 4) out4[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+} // namespace lpb
+} // namespace hv

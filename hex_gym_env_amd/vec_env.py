@@ -27,7 +27,7 @@ def _p(t):
 class HexVecEnv:
     def __init__(self, board_size=11, num_envs=1024, device=None, seed=0, encoding="B",
                  two_sided=False, agent_player_num=None, auto_reset=True, first_player=0,
-                 env_offset=0):
+                 env_offset=0, exact_labels=False):
         if not (_lib.MIN_BOARD <= board_size <= _lib.MAX_BOARD):
             raise ValueError(f"board_size must be in {_lib.MIN_BOARD}..{_lib.MAX_BOARD}")
         if encoding not in ("A", "B"):
@@ -60,6 +60,10 @@ class HexVecEnv:
             flags |= _lib.F_TWO_SIDED
         if not auto_reset:
             flags |= _lib.F_NO_AUTO_RESET
+        if exact_labels:
+            flags |= _lib.F_EXACT_LABELS
+        # auto-reset handles run on the lane-per-board kernels (include/hexvec.h)
+        self.exact = (not auto_reset) or exact_labels or board_size < 4
         self.board_size, self.num_envs, self.encoding = board_size, num_envs, encoding
         self.two_sided, self.auto_reset, self.flags = two_sided, auto_reset, flags
         self.cells = board_size * board_size
@@ -167,9 +171,13 @@ class HexVecEnv:
         return self._rollout(self._L.hexvec_rollout_selfplay, T, out)
 
     def get_state(self):
+        """(board int8 [E,N*N], labels uint8 [E,2,(N+2)^2] or None, cur uint8 [E]).
+
+        labels (the reference's `regions`) exist only on exact handles
+        (auto_reset=False or exact_labels=True)."""
         E, P, dev = self.num_envs, (self.board_size + 2) ** 2, self.device
         board = torch.empty((E, self.cells), dtype=torch.int8, device=dev)
-        labels = torch.empty((E, 2, P), dtype=torch.uint8, device=dev)
+        labels = torch.empty((E, 2, P), dtype=torch.uint8, device=dev) if self.exact else None
         cur = torch.empty(E, dtype=torch.uint8, device=dev)
         _lib.check(self._L.hexvec_get_state(self._h, _p(board), _p(labels), _p(cur), self._stream()))
         return board, labels, cur

@@ -24,6 +24,16 @@
  *   - board_size 2..14 (labels are one byte, a padded plane is one dword per
  *     lane); larger boards are rejected with HEXVEC_E_ARG.
  *
+ * Two kernel families serve a handle, chosen at create time:
+ *   - auto-reset handles (the default) run on the lane-per-board kernels: one
+ *     lane owns one board, connectivity by union-find.  winner / done / reward /
+ *     obs / legal mask are bit-exact; the reference's internal label planes are
+ *     not kept (hexvec_get_state(labels != NULL) and hexvec_apply_moves return
+ *     HEXVEC_E_MODE).
+ *   - HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS handles run on the
+ *     wave-per-board kernels, a literal restatement that also reproduces
+ *     `regions`, illegal plies without state change and plies after the end.
+ *
  * Random numbers (only when the library picks an action): counter based,
  *   key  = mix32(env_global * 0x9E3779B9 + seed_lo) ^ seed_hi
  *   draw = mix32(key + ctr * 0x9E3779B9), ctr++ per draw, per env
@@ -59,6 +69,7 @@ typedef struct hexvec hexvec_t;
 #define HEXVEC_F_NO_AUTO_RESET 0x8u /* finished envs are not restarted inside step               */
 #define HEXVEC_F_FIRST_WHITE 0x10u  /* enc A: constructor current_player_num = WHITE (HexGame.py:155) */
 #define HEXVEC_F_TWO_SIDED 0x20u    /* no in-env opponent: step = one ply of whoever is to move  */
+#define HEXVEC_F_EXACT_LABELS 0x40u /* keep the reference's label planes (regions) bit for bit; see below */
 
 /* Allocates the internal state for num_envs boards on device_id and resets
  * them (replaces HexEnv.__init__ HexGame.py:152-197 / HexSingleGame.py:163-196,

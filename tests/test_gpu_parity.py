@@ -163,20 +163,30 @@ def _flags(enc, two_sided, agent, auto_reset, first):
     return f
 
 
-def _pair(hx, n, E, enc, two_sided=False, agent=None, auto_reset=True, first=0, seed=7, off=0):
+FAMILIES = pytest.mark.parametrize("exact", [False, True], ids=["lane-per-board", "wave-per-board"])
+
+
+def _pair(hx, n, E, enc, two_sided=False, agent=None, auto_reset=True, first=0, seed=7, off=0,
+          exact=False):
     g = hx.HexVecEnv(n, E, encoding=enc, two_sided=two_sided, agent_player_num=agent,
-                     auto_reset=auto_reset, first_player=first, seed=seed, env_offset=off)
+                     auto_reset=auto_reset, first_player=first, seed=seed, env_offset=off,
+                     exact_labels=exact)
+    assert g.exact == (exact or not auto_reset or n < 4)
+    assert g.last_kernel().startswith("k_hex" if g.exact else "k_lpb")
     o = ho.OracleVec(n, E, seed=seed, flags=_flags(enc, two_sided, agent, auto_reset, first),
                      env_offset=off)
     return g, o
 
 
 def _same_state(g, o):
-    gb, gl, gc = (_np(x) for x in g.get_state())
+    gb, gl, gc = g.get_state()
     ob, ol, oc = o.get_state()
-    assert np.array_equal(gb, ob), "board"
-    assert np.array_equal(gl, ol), "labels"
-    assert np.array_equal(gc, oc), "cur"
+    assert np.array_equal(_np(gb), ob), "board"
+    if g.exact:
+        assert np.array_equal(_np(gl), ol), "labels"
+    else:
+        assert gl is None
+    assert np.array_equal(_np(gc), oc), "cur"
     assert np.array_equal(_np(g.episode_stats()), o.episode_stats()), "episode stats"
 
 
@@ -198,10 +208,11 @@ def test_apply_moves_random_cells_vs_oracle(hx, n, enc):
 @pytest.mark.parametrize("n", [3, 5, 7, 11, 13])
 @pytest.mark.parametrize("enc,agent,first", [("B", None, 0), ("B", 0, 0), ("B", 1, 0),
                                              ("A", None, 0), ("A", None, 1)])
-def test_selfplay_rng_steps_vs_oracle(hx, n, enc, agent, first):
+@FAMILIES
+def test_selfplay_rng_steps_vs_oracle(hx, n, enc, agent, first, exact):
     """W1: RNG agent + RNG opponent + auto reset, many episodes."""
     E, K = 64, 6 * n
-    g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=1234 + n)
+    g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=1234 + n, exact=exact)
     if enc == "B":
         assert np.array_equal(_np(g.agent_colours()), o.agent_colours())
     tob = torch.zeros((E, n, n), dtype=torch.int8, device="cuda")
@@ -219,13 +230,14 @@ def test_selfplay_rng_steps_vs_oracle(hx, n, enc, agent, first):
     _same_state(g, o)
 
 
+@FAMILIES
 @pytest.mark.parametrize("n", [4, 7, 11])
 @pytest.mark.parametrize("enc", ["A", "B"])
-def test_selfplay_external_actions_vs_oracle(hx, n, enc):
+def test_selfplay_external_actions_vs_oracle(hx, n, enc, exact):
     """external agent actions (random cells, some illegal) + RNG opponent."""
     E, K = 64, 5 * n
     rng = np.random.default_rng(n)
-    g, o = _pair(hx, n, E, enc, agent=None, seed=99)
+    g, o = _pair(hx, n, E, enc, agent=None, seed=99, exact=exact)
     for k in range(K):
         a = rng.integers(0, n * n, size=E).astype(np.int32)
         obs, rew, done, legal, win = g.step(a)
@@ -238,12 +250,13 @@ def test_selfplay_external_actions_vs_oracle(hx, n, enc):
     _same_state(g, o)
 
 
+@FAMILIES
 @pytest.mark.parametrize("n", [3, 6, 11, 14])
 @pytest.mark.parametrize("enc", ["A", "B"])
-def test_two_sided_steps_and_masked_reset_vs_oracle(hx, n, enc):
+def test_two_sided_steps_and_masked_reset_vs_oracle(hx, n, enc, exact):
     E, K = 64, 4 * n
     rng = np.random.default_rng(n + 50)
-    g, o = _pair(hx, n, E, enc, two_sided=True, seed=5, first=1 if enc == "A" else 0)
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=5, first=1 if enc == "A" else 0, exact=exact)
     for k in range(K):
         a = rng.integers(0, n * n, size=E).astype(np.int32) if k % 3 else None
         obs, rew, done, legal, win = g.step(a)
@@ -262,12 +275,13 @@ def test_two_sided_steps_and_masked_reset_vs_oracle(hx, n, enc):
     _same_state(g, o)
 
 
+@FAMILIES
 @pytest.mark.parametrize("n", [2, 5, 8, 11, 13, 14])
 @pytest.mark.parametrize("enc", ["A", "B"])
-def test_rollout_random_vs_oracle(hx, n, enc):
+def test_rollout_random_vs_oracle(hx, n, enc, exact):
     """W2: device-resident rollout, every ply recorded, vs the oracle's loop."""
     E, T = 80, 2 * n * n + 7
-    g, o = _pair(hx, n, E, enc, two_sided=True, seed=2024)
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=2024, exact=exact)
     out = g.rollout_random(T)
     oobs, olegal, oact, orew, odone = o.rollout(T)
     assert np.array_equal(_np(out["obs"]), oobs)
@@ -284,11 +298,12 @@ def test_rollout_random_vs_oracle(hx, n, enc):
     _same_state(g, o)
 
 
+@FAMILIES
 @pytest.mark.parametrize("n", [5, 11])
 @pytest.mark.parametrize("enc", ["A", "B"])
-def test_rollout_selfplay_vs_oracle(hx, n, enc):
+def test_rollout_selfplay_vs_oracle(hx, n, enc, exact):
     E, T = 64, 4 * n
-    g, o = _pair(hx, n, E, enc, agent=None, seed=31)
+    g, o = _pair(hx, n, E, enc, agent=None, seed=31, exact=exact)
     out = g.rollout_selfplay(T)
     for t in range(T):
         oo, ol, orw, od, ow = o.step()
@@ -362,3 +377,26 @@ def test_errors_are_loud(hx):
         e.rollout_random(4)              # needs a two-sided handle
     with pytest.raises(ValueError):
         e.step(np.zeros(3, np.int32))
+
+
+@pytest.mark.parametrize("n,E", [(5, 70), (11, 65), (7, 1), (4, 129)])
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_lane_per_board_odd_env_counts(hx, n, E, enc):
+    """partial last block of 64 boards and unaligned output rows (byte-store path)"""
+    T = 3 * n
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=77)
+    out = g.rollout_random(T)
+    oobs, olegal, oact, orew, odone = o.rollout(T)
+    assert np.array_equal(_np(out["obs"]), oobs)
+    assert np.array_equal(_np(out["legal"]), olegal)
+    assert np.array_equal(_np(out["actions"]), oact)
+    assert np.array_equal(_np(out["done"]), odone)
+    g2, o2 = _pair(hx, n, E, enc, agent=None, seed=78)
+    for k in range(2 * n):
+        obs, rew, done, legal, win = g2.step()
+        oo, ol, orw, od, ow = o2.step()
+        assert np.array_equal(_np(obs).reshape(E, -1), oo), k
+        assert np.array_equal(_np(legal), ol), k
+        assert np.array_equal(_np(rew), orw), k
+        assert np.array_equal(_np(done), od), k
+    _same_state(g2, o2)
