@@ -36,11 +36,12 @@ def cpu_baseline(board, seconds=12.0):
     E = 4096
     o = ho.OracleVec(board, E, seed=0, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
     o.set_threads(cores)
+    o.step_repeat(4)                      # thread start-up, page faults
     t0 = time.perf_counter()
-    o.step_repeat(8)
+    o.step_repeat(400)
     dt = time.perf_counter() - t0
-    K = max(8, int(8 * seconds / max(dt, 1e-6)))
-    K = min(K, 200000)
+    K = max(400, int(400 * seconds / max(dt, 1e-6)))
+    K = min(K, 2000000)
     t0 = time.perf_counter()
     o.step_repeat(K)
     dt = time.perf_counter() - t0
@@ -104,6 +105,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     run_steps(args.warmup)
+    main_kernel = env.last_kernel()
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -138,6 +140,34 @@ def main():
         extra["host_stepped_env_steps_per_s"] = world * E * ks / (time.perf_counter() - t0)
         extra["host_stepped_bytes_per_step"] = 3 * C + 9
 
+    # W2: two-sided device-resident rollout, every ply recorded (SURVEY 8(d) unit W2)
+    if not args.no_host_stepped:
+        del out
+        env2 = hx.HexVecEnv(N, E, device=dev, encoding="B", two_sided=True, seed=1, env_offset=rank * E)
+        T2 = 64
+        out2 = dict(obs=torch.empty((T2, E, C), dtype=torch.int8, device=dev),
+                    legal=torch.empty((T2, E, C), dtype=torch.uint8, device=dev),
+                    actions=torch.empty((T2, E), dtype=torch.int32, device=dev),
+                    reward=torch.empty((T2, E), dtype=torch.float32, device=dev),
+                    done=torch.empty((T2, E), dtype=torch.uint8, device=dev))
+        for _ in range(2):
+            env2.rollout_random(T2, out2)
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nl = 8
+        for _ in range(nl):
+            env2.rollout_random(T2, out2)
+        e1.record()
+        fence()
+        ms = e0.elapsed_time(e1) / nl
+        plies = E * T2 / (ms * 1e-3)
+        extra["rollout_w2"] = {"plies_per_s": world * plies, "avg_launch_ms": ms,
+                               "bytes_per_ply": 2 * C + 9,
+                               "achieved_GBps": plies * (2 * C + 9) / 1e9,
+                               "frac": plies * (2 * C + 9) / 1e9 / HBM_PEAK_GBPS,
+                               "kernel": env2.last_kernel()}
+
     # episode statistics: the only cross-GPU exchange (logging), one all-gather over RCCL
     stats = env.episode_stats()
     if world > 1:
@@ -161,7 +191,7 @@ def main():
                        "steps_per_launch": T, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_hex<N,B,rollout1>", "bytes_per_env_step": bytes_per_step,
+                         "kernel": main_kernel, "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_GBPS},
             "episodes": {"sum_return": stats[0], "sum_len": stats[1], "n": stats[2],
