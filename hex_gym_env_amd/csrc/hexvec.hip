@@ -53,7 +53,7 @@ constexpr int PLANE_WORDS = 3 * 64; // per env: L0, L1, F|FT<<4   (768 B)
 constexpr int HOT_WORDS = 8;  // per env: counters touched every step (32 B)
 constexpr int STAT_WORDS = 4; // per env: episode sums, touched at episode end
 
-enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4 };
+enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5 };
 
 struct KArgs {
     unsigned char *fast; // lane-per-board state (fast handles)
@@ -75,6 +75,9 @@ struct KArgs {
     signed char *tobs;
     signed char *rblack;
     int *actions_out;
+    const signed char *board_in;   // M_SETSTATE
+    const unsigned char *labels_in; // M_SETSTATE (optional)
+    int cur_in;
 };
 
 // ------------------------------------------------------------------ helpers
@@ -376,7 +379,13 @@ __global__ __launch_bounds__(64 * WPB) void k_hex(KArgs a)
     const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
     const bool auto_reset = (a.flags & HEXVEC_F_NO_AUTO_RESET) == 0;
 
-    if (MODE == M_RESET && a.init) {
+    if (MODE == M_SETSTATE) {
+        const u32 hw = lane < HOT_WORDS ? hot[lane] : 0u;
+        s.ctr = rdlane(hw, 0);
+        s.agent = (rdlane(hw, 3) >> 3) & 1;
+        s.winner = -1;
+        E_::fresh(s, 0);
+    } else if (MODE == M_RESET && a.init) {
         s.ctr = 0;
         s.winner = -1;
         s.agent = !B ? 0 : (a.flags & HEXVEC_F_AGENT_RANDOM) ? (int)(mix32(s.key ^ 0xA5A5A5A5U) & 1u)
@@ -407,7 +416,62 @@ __global__ __launch_bounds__(64 * WPB) void k_hex(KArgs a)
     const size_t E = (size_t)a.E;
     int sr = 0, sl = 0, se = 0, sw = 0; // episode sums finished in this launch
 
-    if (MODE == M_RESET) {
+    if (MODE == M_SETSTATE) {
+        // HexGame.__init__ (HexGame.py:21-68 / HexSingleGame.py:26-71) on a given board
+        const signed char *bd = a.board_in + (size_t)env * G::C;
+        E_::fresh(s, a.cur_in);
+        if (a.labels_in) { // connected_stones adopted (:46-47), region_counter = max + 1 (:49-51)
+            u32 f = s.fi, ft = s.fi, l0 = 0, l1 = 0, mx0 = 0, mx1 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = j * 64 + (int)lane;
+                if (q < G::P) {
+                    const u32 b0 = a.labels_in[((size_t)env * 2 + 0) * G::P + q];
+                    const u32 b1 = a.labels_in[((size_t)env * 2 + 1) * G::P + q];
+                    l0 |= b0 << (8 * j);
+                    l1 |= b1 << (8 * j);
+                    mx0 = max(mx0, b0);
+                    mx1 = max(mx1, b1);
+                }
+                if (q < G::C) {
+                    const int y = q / N, x = q - y * N;
+                    const int v = bd[q], vt = bd[x * N + y];
+                    const u32 c = B ? (v == -1 ? 1u : (v == 1 ? 2u : 0u)) : (v == 0 ? 1u : (v == 1 ? 2u : 0u));
+                    const u32 ct = B ? (vt == -1 ? 1u : (vt == 1 ? 2u : 0u)) : (vt == 0 ? 1u : (vt == 1 ? 2u : 0u));
+                    f |= c << (8 * j);
+                    ft |= ct << (8 * j);
+                }
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                mx0 = max(mx0, (u32)__shfl_xor((int)mx0, off));
+                mx1 = max(mx1, (u32)__shfl_xor((int)mx1, off));
+            }
+            s.L0 = l0;
+            s.L1 = l1;
+            s.F = f;
+            s.FT = ft;
+            s.nx0 = (int)rflu(mx0) + 1;
+            s.nx1 = (int)rflu(mx1) + 1;
+            int ne = 0;
+#pragma unroll
+            for (int j = 0; j < G::J; ++j) ne += __popcll(__ballot(((f >> (8 * j)) & 0xffu) == 0u));
+            s.n_empty = ne;
+        } else { // replay the stones row-major through flood_fill (:53-61 / :57-65)
+            for (int c = 0; c < G::C; ++c) {
+                const int v = rfl((int)bd[c]);
+                const int p = B ? (v == -1 ? 0 : (v == 1 ? 1 : -1)) : (v == 0 ? 0 : (v == 1 ? 1 : -1));
+                if (p < 0) continue;
+                const int y = c / N, x = c - y * N;
+                s.F = put_byte(s.F, c, (u32)p + 1u, lane);
+                s.FT = put_byte(s.FT, x * N + y, (u32)p + 1u, lane);
+                s.n_empty -= 1;
+                const int q = (y + 1) * G::W + (x + 1); // untransposed for both colours
+                if (p) s.L1 = E_::flood_fill(s.L1, q, s.nx1, lane, s.nboff);
+                else s.L0 = E_::flood_fill(s.L0, q, s.nx0, lane, s.nboff);
+            }
+        }
+        s.winner = -1;
+    } else if (MODE == M_RESET) {
         const bool sel = a.env_mask ? (rfl((int)a.env_mask[env]) != 0) : true;
         if (sel || a.init) E_::reset_env(s, a.flags, a.opp_actions, env, lane);
         E_::emit(s, a.obs ? a.obs + (size_t)env * G::C : nullptr,
@@ -622,6 +686,7 @@ template <int N, int ENC> static hipError_t launch_mode(int mode, const KArgs &a
     case M_ROLLOUT2: return launch1<N, ENC, M_ROLLOUT2>(a, st);
     case M_STEP: return launch1<N, ENC, M_STEP>(a, st);
     case M_ROLLOUT1: return launch1<N, ENC, M_ROLLOUT1>(a, st);
+    case M_SETSTATE: return launch1<N, ENC, M_SETSTATE>(a, st);
     default: return launch1<N, ENC, M_RESET>(a, st);
     }
 }
@@ -734,6 +799,7 @@ static const char *kname(int mode)
     case M_ROLLOUT2: return "k_hex<rollout2>";
     case M_STEP: return "k_hex<step>";
     case M_ROLLOUT1: return "k_hex<rollout1>";
+    case M_SETSTATE: return "k_hex<set_state>";
     default: return "k_hex<reset>";
     }
 }
@@ -951,6 +1017,22 @@ extern "C" int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uin
                        (h->flags & HEXVEC_F_ENC_B) ? 1 : 0, (signed char *)board, labels, cur_player);
     HV_HIP(hipGetLastError());
     return HEXVEC_OK;
+}
+
+extern "C" int hexvec_set_state(hexvec_t *h, const int8_t *board, const uint8_t *labels, int cur_player,
+                                void *stream)
+{
+    HV_HANDLE(h);
+    if (h->fast_mode)
+        return fail(HEXVEC_E_MODE, "%s",
+                    "hexvec_set_state needs a HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS handle");
+    if (!board || (cur_player != 0 && cur_player != 1))
+        return fail(HEXVEC_E_ARG, "%s", "board is NULL or cur_player not 0/1");
+    hv::KArgs a = hv::base_args(h);
+    a.board_in = (const signed char *)board;
+    a.labels_in = labels;
+    a.cur_in = cur_player;
+    return hv::run(h, hv::M_SETSTATE, a, stream);
 }
 
 extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)

@@ -1,0 +1,48 @@
+"""Multi-GPU layout: boards shard trivially.
+
+One process per GPU (torchrun); rank r owns global envs [r*E, (r+1)*E) and passes
+env_offset = r*E, so the counter RNG (keyed by the global env id) makes results
+independent of the number of GPUs.  The step path has no collective; the only
+exchange is one all_gather of 4 doubles per rank for logging (RCCL over xGMI on
+GPUs, gloo in the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_range(total_envs, rank=None, world=None):
+    """contiguous env range [lo, hi) of `rank`; sizes differ by at most one"""
+    if rank is None or world is None:
+        rank, world = rank_world()
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(int(total_envs), world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_episode_stats(local_stats):
+    """local_stats: float64 [4] (sum_return, sum_len, n_episodes, n_agent_wins) on this rank's
+    device -> (per-rank [world, 4], totals [4]).  One all_gather; a no-op without a process group."""
+    local_stats = local_stats.to(torch.float64).reshape(4)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        per = local_stats.unsqueeze(0)
+        return per, per.sum(0)
+    bufs = [torch.empty_like(local_stats) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, local_stats)
+    per = torch.stack(bufs)
+    return per, per.sum(0)
+
+
+def summarize(totals):
+    t = [float(x) for x in totals]
+    n = max(t[2], 1.0)
+    return {"episodes": t[2], "ep_rew_mean": t[0] / n, "ep_len_mean": t[1] / n, "agent_win_rate": t[3] / n}

@@ -1,0 +1,127 @@
+"""HexSB3VecEnv: the stable-baselines3 `VecEnv` contract on top of HexVecEnv.
+
+What sb3_contrib's MaskablePPO needs from a vectorised env: num_envs,
+observation_space, action_space, reset() -> obs, step_async(actions), step_wait() ->
+(obs, rewards, dones, infos) with auto reset, infos[i]["terminal_observation"] and
+infos[i]["episode"] = {"r","l","t"} for finished envs, env_method("action_masks"),
+has_attr("action_masks").  SB3 is optional: when it is importable this class derives
+from stable_baselines3.common.vec_env.VecEnv, otherwise it is a plain class with the
+same methods (the build image has no SB3).
+
+The SB3 contract is numpy on the host; that round trip dominates at tens of thousands
+of envs.  Use HexVecEnv directly (torch tensors on the device) for throughput.
+"""
+import time
+
+import numpy as np
+import torch
+
+from ._compat import spaces
+from .vec_env import HexVecEnv
+
+try:  # pragma: no cover
+    from stable_baselines3.common.vec_env import VecEnv as _Base
+    HAVE_SB3 = True
+except Exception:
+    _Base = object
+    HAVE_SB3 = False
+
+
+class HexSB3VecEnv(_Base):
+    def __init__(self, board_size=5, num_envs=64, agent_player_num=None, seed=0, device=None,
+                 encoding="B"):
+        self.vec = HexVecEnv(board_size, num_envs, device=device, seed=seed, encoding=encoding,
+                             agent_player_num=agent_player_num)
+        n = board_size
+        lo, hi = (-1, 1) if encoding == "B" else (0, 2)
+        obs_space = spaces.Box(low=lo, high=hi, shape=(n, n), dtype=np.int8)
+        act_space = spaces.Discrete(n * n)
+        if HAVE_SB3:
+            super().__init__(num_envs, obs_space, act_space)
+        else:
+            self.num_envs, self.observation_space, self.action_space = num_envs, obs_space, act_space
+        self._tobs = torch.zeros((num_envs, n, n), dtype=torch.int8, device=self.vec.device)
+        self._actions = None
+        self._ep_ret = np.zeros(num_envs, np.float64)
+        self._ep_len = np.zeros(num_envs, np.int64)
+        self._t0 = time.time()
+        self._masks = None
+        self._infos = [{} for _ in range(num_envs)]
+        self.render_mode = None
+
+    # -- VecEnv API ---------------------------------------------------------
+    def reset(self):
+        obs, legal = self.vec.reset()
+        self._masks = legal.cpu().numpy().astype(bool)
+        self._ep_ret[:] = 0
+        self._ep_len[:] = 0
+        return obs.cpu().numpy()
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions)
+
+    def step_wait(self):
+        obs, rew, done, legal, _ = self.vec.step(self._actions, terminal_obs=self._tobs)
+        obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
+        done_h = done.cpu().numpy().astype(bool)
+        self._masks = legal.cpu().numpy().astype(bool)
+        self._ep_ret += rew_h
+        self._ep_len += 1
+        for i in self._dirty:
+            self._infos[i] = {}
+        self._dirty = np.flatnonzero(done_h)
+        if len(self._dirty):
+            tobs = self._tobs.cpu().numpy()
+            now = time.time() - self._t0
+            for i in self._dirty:
+                self._infos[i] = {"terminal_observation": tobs[i].copy(), "TimeLimit.truncated": False,
+                                  "episode": {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]),
+                                              "t": now}}
+            self._ep_ret[self._dirty] = 0
+            self._ep_len[self._dirty] = 0
+        return obs_h, rew_h, done_h, self._infos
+
+    _dirty = ()
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def action_masks(self):
+        return self._masks
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = self._indices(indices)
+        if method_name == "action_masks":
+            return [self._masks[i] for i in idx]
+        raise AttributeError(f"HexSB3VecEnv has no per-env method {method_name!r}")
+
+    def has_attr(self, attr_name):
+        return attr_name in ("action_masks", "board_size")
+
+    def get_attr(self, attr_name, indices=None):
+        idx = self._indices(indices)
+        if attr_name == "board_size":
+            return [self.vec.board_size for _ in idx]
+        if attr_name == "render_mode":
+            return [None for _ in idx]
+        raise AttributeError(attr_name)
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise AttributeError("HexSB3VecEnv attributes are fixed at construction")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False for _ in self._indices(indices)]
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs
+
+    def close(self):
+        self.vec.close()
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return indices

@@ -182,6 +182,19 @@ class HexVecEnv:
         _lib.check(self._L.hexvec_get_state(self._h, _p(board), _p(labels), _p(cur), self._stream()))
         return board, labels, cur
 
+    def set_state(self, board, labels=None, cur_player=0):
+        """HexGame.__init__ on given boards (exact handles): board int8 [E,N*N] in this handle's
+        encoding; labels uint8 [E,2,(N+2)^2] adopted as connected_stones, or None to rebuild."""
+        b = torch.as_tensor(board, device=self.device).to(torch.int8).contiguous()
+        if b.numel() != self.num_envs * self.cells:
+            raise ValueError("board must have E*N*N elements")
+        l = None
+        if labels is not None:
+            l = torch.as_tensor(labels, device=self.device).to(torch.uint8).contiguous()
+            if l.numel() != self.num_envs * 2 * (self.board_size + 2) ** 2:
+                raise ValueError("labels must have E*2*(N+2)^2 elements")
+        _lib.check(self._L.hexvec_set_state(self._h, _p(b), _p(l), int(cur_player), self._stream()))
+
     def episode_stats(self):
         """float64 [4] on the device: sum_return, sum_len, n_episodes, n_agent_wins."""
         out = torch.empty(4, dtype=torch.float64, device=self.device)

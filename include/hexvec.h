@@ -131,6 +131,14 @@ int hexvec_rollout_selfplay(hexvec_t *h, int T, int8_t *obs /* [T,E,N*N] */, uin
 int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uint8_t *cur_player,
                      void *stream);
 
+/* Replace the position of every env (exact handles only): HexGame.__init__ on a given
+ * board, HexGame.py:21-68 / HexSingleGame.py:26-71.  board int8 [E,N*N] in the handle's
+ * encoding (frame of BLACK to move); labels uint8 [E,2,(N+2)^2] are adopted like
+ * `connected_stones` (:46-51) or, when NULL, rebuilt by replaying the stones row-major
+ * (:53-61); cur_player = constructor current_player_num / active_player. */
+int hexvec_set_state(hexvec_t *h, const int8_t *board, const uint8_t *labels, int cur_player,
+                     void *stream);
+
 /* out4 (device, double[4]) = sum of episode returns, sum of episode lengths,
  * episodes finished, episodes the agent (TWO_SIDED: BLACK) won -- since create. */
 int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream);

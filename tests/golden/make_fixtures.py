@@ -319,6 +319,23 @@ def gen_preplaced(HexGameA, playerA, HexGameB, sizes, rng):
     return out
 
 
+def gen_sample_board(HexEnvB, sizes):
+    """HexEnv(sample_board=True): HexSingleGame.py:174-177, :217-222, :300-331 under np.random seeds"""
+    out = {}
+    for n in sizes:
+        for k in range(6):
+            np.random.seed(500 + 10 * n + k)
+            env = HexEnvB(board_size=n, sample_board=True)
+            out[f"N{n}_s{k}_init_board"] = env.initial_board.astype(np.int8)
+            b = env.reset()
+            out[f"N{n}_s{k}_reset_board"] = b.astype(np.int8).copy()
+            out[f"N{n}_s{k}_regions"] = env.simulator.regions.astype(np.uint8)
+            b2 = env.reset()
+            out[f"N{n}_s{k}_reset2_board"] = b2.astype(np.int8).copy()
+    out["sizes"] = np.array(sizes, dtype=np.int32)
+    return out
+
+
 def gen_render(HexEnvA, playerA, HexEnvB, random_policy):
     texts = {}
     for n in (3, 5):
@@ -369,6 +386,7 @@ def main():
                         **gen_env_a(HexEnvA, playerA, random_policy, [3, 5, 7], rng))
     np.savez_compressed(os.path.join(OUT, "preplaced.npz"),
                         **gen_preplaced(HexGameA, playerA, HexGameB, [3, 5, 7, 11], rng))
+    np.savez_compressed(os.path.join(OUT, "sample_board.npz"), **gen_sample_board(HexEnvB, [5, 7, 11]))
     for name, (board, text) in gen_render(HexEnvA, playerA, HexEnvB, random_policy).items():
         np.save(os.path.join(OUT, name + "_board.npy"), board)
         with open(os.path.join(OUT, name + ".txt"), "w") as f:

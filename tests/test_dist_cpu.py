@@ -1,0 +1,75 @@
+"""The N>1 path on CPU: two gloo ranks shard the env range and all-gather episode statistics
+exactly as bench.py / hex_gym_env_amd.dist do over RCCL.  The boards themselves come from the
+oracle here (no GPU in this container); the product's kernels are exercised by -m gpu tests."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hex_gym_env_amd.dist import gather_episode_stats, shard_range, summarize
+    from oracle import hex_oracle as ho
+    lo, hi = shard_range(total)
+    env = ho.OracleVec(5, hi - lo, seed=9, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM, env_offset=lo)
+    rews = []
+    for _ in range(40):
+        rews.append(env.step()[2].copy())
+    per, tot = gather_episode_stats(torch.from_numpy(env.episode_stats()))
+    dist.barrier()
+    q.put((rank, lo, hi, np.stack(rews), per.numpy(), tot.numpy(), summarize(tot)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_stats_gather():
+    world, total = 2, 101                      # uneven split on purpose
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from oracle import hex_oracle as ho
+    full = ho.OracleVec(5, total, seed=9, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
+    rews = np.stack([full.step()[2].copy() for _ in range(40)])
+    (r0, lo0, hi0, rw0, per0, tot0, s0), (r1, lo1, hi1, rw1, per1, tot1, s1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 51, 51, 101)
+    assert np.array_equal(np.concatenate([rw0, rw1], axis=1), rews)      # sharding invariance
+    assert np.array_equal(per0, per1) and per0.shape == (2, 4)
+    assert np.array_equal(tot0, full.episode_stats()) and np.array_equal(tot0, tot1)
+    assert s0 == s1 and s0["episodes"] == full.episode_stats()[2]
+
+
+def test_shard_range_covers_everything():
+    from hex_gym_env_amd.dist import shard_range
+    for total in (1, 7, 64, 65536, 524288):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
