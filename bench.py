@@ -30,21 +30,22 @@ HBM_COPY_GBPS = 6290.0
 
 
 def cpu_baseline(board, seconds=12.0):
-    """The oracle (a C port of the reference algorithm) on this host's cores, same workload."""
+    """The oracle (a C port of the reference algorithm) on this host's cores, same workload,
+    run in chunks until `seconds` of CPU work have been timed."""
     from oracle import hex_oracle as ho
     cores = os.cpu_count() or 1
     E = 4096
     o = ho.OracleVec(board, E, seed=0, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
     o.set_threads(cores)
-    o.step_repeat(4)                      # thread start-up, page faults
+    o.step_repeat(50)                      # thread start-up, page faults
+    K, chunk = 0, 2000
     t0 = time.perf_counter()
-    o.step_repeat(400)
-    dt = time.perf_counter() - t0
-    K = max(400, int(400 * seconds / max(dt, 1e-6)))
-    K = min(K, 2000000)
-    t0 = time.perf_counter()
-    o.step_repeat(K)
-    dt = time.perf_counter() - t0
+    while True:
+        o.step_repeat(chunk)
+        K += chunk
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
     return {"value": E * K / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{E} envs x {K} self-play steps, {board}x{board}, oracle/hex_oracle.c "
                       f"on {cores} threads, {dt:.1f} s"}
@@ -53,8 +54,8 @@ def cpu_baseline(board, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--board", type=int, default=11)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--chunk", type=int, default=50, help="env steps per rollout launch")
@@ -127,10 +128,22 @@ def main():
     steps_per_launch = args.steps / launches
     achieved = E * steps_per_launch * bytes_per_step / avg_launch_s / 1e9
 
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE is half-counted on gfx950, MI355X_MICROARCH.md HBM section); null if the
+    # profile was taken for another configuration
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.json")))
+        if (prof["config"] == {"board": N, "envs": E, "steps_per_launch": T}
+                and main_kernel.endswith("rollout1>")):
+            traffic = (2 * prof["FETCH_SIZE_KiB"] + prof["WRITE_SIZE_KiB"]) * 1024.0
+    except Exception:
+        traffic = None
+
     extra = {}
     if not args.no_host_stepped:
-        ks = min(args.steps, 500)
-        for _ in range(20):
+        ks = min(args.steps, 1000)
+        for _ in range(100):
             env.step()
         fence()
         t0 = time.perf_counter()
@@ -150,12 +163,12 @@ def main():
                     actions=torch.empty((T2, E), dtype=torch.int32, device=dev),
                     reward=torch.empty((T2, E), dtype=torch.float32, device=dev),
                     done=torch.empty((T2, E), dtype=torch.uint8, device=dev))
-        for _ in range(2):
+        for _ in range(10):
             env2.rollout_random(T2, out2)
         fence()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nl = 8
+        nl = 40
         for _ in range(nl):
             env2.rollout_random(T2, out2)
         e1.record()
@@ -190,7 +203,7 @@ def main():
                        "board_size": N, "envs_per_gpu": E, "global_envs": world * E,
                        "steps_per_launch": T, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": main_kernel, "bytes_per_env_step": bytes_per_step,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "frac_of_copy_ceiling": achieved / HBM_COPY_GBPS},

@@ -33,12 +33,12 @@ SYMBOLS = [
 
 def build(force=False):
     """Compile libhexvec.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, "hexvec.hip")
-    hdr = os.path.join(_HERE, "..", "include", "hexvec.h")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "hexvec.h"))
     stale = (not os.path.exists(SO_PATH)
-             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(SO_PATH) < max(os.path.getmtime(f) for f in srcs))
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", CSRC, "libhexvec.so"])
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC, "libhexvec.so"])
     return SO_PATH
 
 

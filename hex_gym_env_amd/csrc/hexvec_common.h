@@ -1,0 +1,97 @@
+// hexvec_common.h -- declarations shared by the translation units of libhexvec.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "hexvec.h"
+
+namespace hv {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+constexpr int WPB = 4;        // wavefronts (= boards) per workgroup
+constexpr int PLANE_WORDS = 3 * 64; // per env: L0, L1, F|FT<<4   (768 B)
+constexpr int HOT_WORDS = 8;  // per env: counters touched every step (32 B)
+constexpr int STAT_WORDS = 4; // per env: episode sums, touched at episode end
+
+enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5 };
+
+struct KArgs {
+    unsigned char *fast; // lane-per-board state (fast handles)
+    u32 *planes;
+    u32 *hot;
+    int *stats;
+    int E;
+    u32 env_offset, seed_lo, seed_hi, flags;
+    int T;
+    int init;
+    const int *actions;
+    const int *opp_actions;
+    const unsigned char *env_mask;
+    signed char *obs;
+    unsigned char *legal;
+    float *reward;
+    unsigned char *done;
+    signed char *winner;
+    signed char *tobs;
+    signed char *rblack;
+    int *actions_out;
+    const signed char *board_in;   // M_SETSTATE
+    const unsigned char *labels_in; // M_SETSTATE (optional)
+    int cur_in;
+};
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ u32 mix32(u32 x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 rflu(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u32 rdlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u32 mbcnt(u64 m)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+}
+// byte `idx` of a striped plane (idx wave-uniform -> result wave-uniform)
+__device__ __forceinline__ u32 byte_at(u32 reg, int idx)
+{
+    return (rdlane(reg, idx & 63) >> ((idx >> 6) * 8)) & 0xffu;
+}
+__device__ __forceinline__ u32 put_byte(u32 reg, int idx, u32 val, u32 lane)
+{
+    const int sh = (idx >> 6) * 8;
+    const u32 nw = (reg & ~(0xffu << sh)) | (val << sh);
+    return lane == (u32)(idx & 63) ? nw : reg;
+}
+
+
+// launchers, one per translation unit (so the kernel families compile in parallel)
+hipError_t wpb_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
+hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int enc, signed char *board,
+                         unsigned char *labels, unsigned char *cur, hipStream_t st);
+hipError_t wpb_stats(const int *stats, int E, double *out4, hipStream_t st);
+hipError_t wpb_agents(const u32 *hot, int E, unsigned char *out, hipStream_t st);
+
+hipError_t lpb64_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
+size_t lpb64_block_bytes(int N, int enc);
+hipError_t lpb64_get_state(const unsigned char *fast, int N, int enc, int E, signed char *board,
+                           unsigned char *cur, hipStream_t st);
+hipError_t lpb64_stats(const unsigned char *fast, int N, int enc, int E, double *out4,
+                       unsigned char *agents, hipStream_t st);
+hipError_t lpb32_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
+size_t lpb32_block_bytes(int N, int enc);
+hipError_t lpb32_get_state(const unsigned char *fast, int N, int enc, int E, signed char *board,
+                           unsigned char *cur, hipStream_t st);
+hipError_t lpb32_stats(const unsigned char *fast, int N, int enc, int E, double *out4,
+                       unsigned char *agents, hipStream_t st);
+
+} // namespace hv

@@ -11,11 +11,13 @@
 //                     frame (BLACK: y*N+x, WHITE: x*N+y, so both connect
 //                     row 0 with row N-1 and the hex neighbourhood is the same
 //                     six offsets).  0 = no stone of p; 1..C = child, parent
-//                     index + 1; 0xFC|f = root, f bit0/bit1 = its group touches
-//                     row 0 / row N-1.  A new stone becomes the root of every
-//                     group it touches (6 neighbour reads, pointer chase, OR
-//                     of the root flags); the mover wins iff its root flags
-//                     become 3.  That is plain connectivity, which SURVEY 4
+//                     index + 1; 0xE0 | rank<<2 | f = root, f bit0/bit1 = its
+//                     group touches row 0 / row N-1.  A new stone reads its 6
+//                     neighbours, chases them to their roots (all chains of all
+//                     64 boards in lockstep), hangs itself and the lower-rank
+//                     roots under the highest-rank root (union by rank: the
+//                     wave-level chase depth stays ~2) and ORs the flags; the
+//                     mover wins iff the flags become 3.  That is plain connectivity, which SURVEY 4
 //                     verified equals the reference's label merging
 //                     (HexGame.py:124-142 + :101-105).
 //   IMG[v][board][C]  the observation bytes themselves, packed exactly as the
@@ -35,31 +37,35 @@
 // quirks (q1/q2 of SURVEY 8a) cannot be observed; handles created with
 // HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS use the wave-per-board
 // kernels, which keep the reference's label planes bit for bit.
+// Included by hexvec_lpb64.hip / hexvec_lpb32.hip with HV_BPW = boards per wavefront
+// (64: every lane owns a board; 32: the upper half-wave only helps in the cooperative
+// copies, LDS per wave halves and two waves fit per SIMD) and HV_LPB_NAME(x) = lpbNN_##x.
 #pragma once
+#include "hexvec_common.h"
 
 namespace hv {
 namespace lpb {
 
-template <int N> struct Geo {
+template <int N, int BPW> struct Geo {
     static constexpr int C = N * N;
     static constexpr int JW = (C + 31) / 32; // bitboard words
     static constexpr int PS0 = (C + 2 + 3) / 4 * 4;
     static constexpr int PS = ((PS0 / 4) % 2 == 0) ? PS0 + 4 : PS0; // odd dword stride: lanes spread over banks
     static constexpr int DUMMY = C;     // always 0: stands in for off-board neighbours
     static constexpr int TRASH = C + 1; // absorbs predicated-off writes
-    static constexpr int UF_BYTES = 2 * 64 * PS;
-    static constexpr int IMG_BYTES = 64 * C; // per view; multiple of 16
-    static constexpr int NIT = (4 * C + 63) / 64; // 16-byte vectors per view / 64 lanes
+    static constexpr int UF_BYTES = 2 * BPW * PS;
+    static constexpr int IMG_BYTES = BPW * C; // per view; multiple of 16
+    static constexpr int NIT = (BPW * C / 16 + 63) / 64; // 16-byte vectors per view / 64 lanes
 };
 
 // per-lane registers persisted between launches: [REGW][64] words per block
 template <int N> struct Regs {
-    static constexpr int JW = Geo<N>::JW;
+    static constexpr int JW = (N * N + 31) / 32;
     static constexpr int REGW = 2 * JW + 8;
 };
 
-template <int N, int ENC> struct Lpb {
-    using G = Geo<N>;
+template <int N, int ENC, int BPW> struct Lpb {
+    using G = Geo<N, BPW>;
     static constexpr bool B = ENC == 1;
     static constexpr int NV = B ? 2 : 1;
     static constexpr int C = G::C, JW = G::JW, PS = G::PS;
@@ -180,7 +186,7 @@ template <int N, int ENC> struct Lpb {
             lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
         }
         // union-find in p's own frame
-        unsigned char *uf = lds + (p * 64 + lane) * PS;
+        unsigned char *uf = lds + (p * BPW + lane) * PS;
         const int a = p ? idx1 : idx0;
         const int y = a / N, x = a - y * N;
         const bool up = y > 0, dn = y < N - 1, lf = x > 0, rt = x < N - 1;
@@ -204,7 +210,7 @@ template <int N, int ENC> struct Lpb {
             bool ch[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                ch[i] = (e[i] - 1u) < 0xFBu; // 1..0xFB: child
+                ch[i] = (e[i] - 1u) < 0xDFu; // 1..0xDF: child
                 any = any || ch[i];
             }
             if (!__ballot(any)) break;
@@ -214,16 +220,30 @@ template <int N, int ENC> struct Lpb {
                 e[i] = uf[ix[i]];
             }
         }
+        // union by rank: everything hangs under the highest-rank root
         u32 fl = (y == 0 ? 1u : 0u) | (y == N - 1 ? 2u : 0u);
-        const unsigned char child = (unsigned char)(a + 1);
+        int best_rank = -1, best_ix = G::TRASH;
+        int rk[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const bool st = e[i] != 0u; // a root of colour p
+            rk[i] = st ? (int)((e[i] >> 2) & 7u) : -1;
             fl |= st ? (e[i] & 3u) : 0u;
-            uf[st ? ix[i] : G::TRASH] = child; // old root -> child of the new stone
-            uf[st ? nb[i] : G::TRASH] = child; // and the neighbour itself (path compression)
+            const bool better = rk[i] > best_rank;
+            best_ix = better ? ix[i] : best_ix;
+            best_rank = better ? rk[i] : best_rank;
         }
-        uf[a] = (unsigned char)(0xFCu | fl);
+        bool tie = false;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool other = rk[i] >= 0 && ix[i] != best_ix;
+            tie = tie || (other && rk[i] == best_rank);
+            uf[other ? ix[i] : G::TRASH] = (unsigned char)(best_ix + 1);
+        }
+        const bool has = best_rank >= 0;
+        const u32 root_byte = 0xE0u | ((u32)(has ? best_rank + (tie ? 1 : 0) : 0) << 2) | fl;
+        uf[a] = has ? (unsigned char)(best_ix + 1) : (unsigned char)root_byte;
+        uf[has ? best_ix : G::TRASH] = (unsigned char)root_byte;
         return fl == 3u;
     }
 
@@ -235,7 +255,7 @@ template <int N, int ENC> struct Lpb {
             mask &= mask - 1;
 #pragma unroll
             for (int p = 0; p < 2; ++p)
-                if (lane < PS / 4) reinterpret_cast<u32 *>(lds + (p * 64 + d) * PS)[lane] = 0u;
+                if (lane < PS / 4) reinterpret_cast<u32 *>(lds + (p * BPW + d) * PS)[lane] = 0u;
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 for (int i = lane; i < C; i += 64) lds[IMG + v * G::IMG_BYTES + d * C + i] = EMPTY_BYTE;
@@ -254,83 +274,129 @@ template <int N, int ENC> struct Lpb {
         }
     }
 
-    // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`
+    // view merge + legal mask of one 16-byte vector (r0 / r1 = the two views' bytes)
+    static __device__ __forceinline__ void merge_vec(u64 view1, int byte0, const uint4 &r0, const uint4 &r1,
+                                                     uint4 &o, uint4 &l)
+    {
+        o = r0;
+        if (B) {
+            const int b0 = byte0 / C;
+            const int s = C - (byte0 - b0 * C); // bytes [0,s) of this vector belong to board b0
+            const u32 ph = (u32)(view1 >> b0);
+            const u32 m0 = 0u - (ph & 1u), m1 = 0u - ((ph >> 1) & 1u);
+            u32 oo[4] = {r0.x, r0.y, r0.z, r0.w};
+            const u32 rr[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sh = (s - 4 * k) * 8;
+                const u32 T = sh <= 0 ? 0xffffffffu : (sh >= 32 ? 0u : (0xffffffffu << sh)); // bytes >= s
+                const u32 M = (m0 & ~T) | (m1 & T);                                           // bytes taken from view 1
+                oo[k] = (rr[k] & M) | (oo[k] & ~M);
+            }
+            o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+            // values 0x00 / 0x01 / 0xFF: empty <=> bit 0 clear
+            l = make_uint4(~o.x & 0x01010101u, ~o.y & 0x01010101u, ~o.z & 0x01010101u, ~o.w & 0x01010101u);
+        } else { // values 0 / 1 / 2: empty <=> bit 1 set
+            l = make_uint4((o.x >> 1) & 0x01010101u, (o.y >> 1) & 0x01010101u, (o.z >> 1) & 0x01010101u,
+                           (o.w >> 1) & 0x01010101u);
+        }
+    }
+    static __device__ __forceinline__ void emit_vec(const unsigned char *lds, u64 view1, int byte0, uint4 &o, uint4 &l)
+    {
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
+        uint4 r1 = r0;
+        if (B) r1 = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+        merge_vec(view1, byte0, r0, r1, o, l);
+    }
+
+    // tail blocks / unaligned rows: byte stores with bounds (cold, deliberately not unrolled)
+    static __device__ __noinline__ void emit_slow(const unsigned char *lds, u64 view1, signed char *obs,
+                                                  unsigned char *legal, int live_bytes, int lane)
+    {
+#pragma unroll 1
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = (it * 64 + lane) * 16;
+            if (byte0 >= G::IMG_BYTES || byte0 >= live_bytes) continue;
+            uint4 o, l;
+            emit_vec(lds, view1, byte0, o, l);
+            const u32 ow[4] = {o.x, o.y, o.z, o.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) {
+                if (byte0 + k >= live_bytes) break;
+                const u32 wo = k < 4 ? ow[0] : k < 8 ? ow[1] : k < 12 ? ow[2] : ow[3];
+                const u32 wl = k < 4 ? lw[0] : k < 8 ? lw[1] : k < 12 ? lw[2] : lw[3];
+                if (obs) obs[byte0 + k] = (signed char)((wo >> ((k & 3) * 8)) & 0xffu);
+                if (legal) legal[byte0 + k] = (unsigned char)((wl >> ((k & 3) * 8)) & 0xffu);
+            }
+        }
+    }
+
+    // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`.
+    // All LDS reads of the span are issued first, then merged and stored as whole 1 KiB pieces;
+    // only the last piece is partial (lanes past the span re-read the last vector and skip the store).
+    template <bool OBS, bool LEGAL>
+    static __device__ __forceinline__ void emit_fast(const unsigned char *lds, u64 view1, signed char *obs,
+                                                     unsigned char *legal, int lane)
+    {
+        uint4 r0[G::NIT], r1[G::NIT];
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = min((it * 64 + lane) * 16, G::IMG_BYTES - 16);
+            r0[it] = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
+            if (B) r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+        }
+#pragma unroll
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = (it * 64 + lane) * 16;
+            uint4 o, l;
+            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), r0[it], B ? r1[it] : r0[it], o, l);
+            if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
+                if (OBS) *reinterpret_cast<uint4 *>(obs + byte0) = o;
+                if (LEGAL) *reinterpret_cast<uint4 *>(legal + byte0) = l;
+            }
+        }
+    }
     static __device__ __forceinline__ void emit(const unsigned char *lds, u64 view1, signed char *obs,
                                                 unsigned char *legal, int nlive, bool vec_ok, int lane)
     {
         if (!obs && !legal) return;
-        const int live_bytes = nlive * C;
-#pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            const int byte0 = (it * 64 + lane) * 16;
-            if (byte0 >= G::IMG_BYTES) continue;
-            uint4 o = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
-            if (B) {
-                const uint4 r1 = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
-                const int b0 = byte0 / C;
-                const int s = C - (byte0 - b0 * C); // bytes [0,s) of this vector belong to board b0
-                const u32 ph = (u32)(view1 >> b0);
-                const u32 m0 = 0u - (ph & 1u), m1 = 0u - ((ph >> 1) & 1u);
-                u32 oo[4] = {o.x, o.y, o.z, o.w};
-                const u32 rr[4] = {r1.x, r1.y, r1.z, r1.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int sh = (s - 4 * k) * 8;
-                    const u32 T = sh <= 0 ? 0xffffffffu : (sh >= 32 ? 0u : (0xffffffffu << sh)); // bytes >= s
-                    const u32 M = (m0 & ~T) | (m1 & T);                                           // bytes taken from view 1
-                    oo[k] = (rr[k] & M) | (oo[k] & ~M);
-                }
-                o = make_uint4(oo[0], oo[1], oo[2], oo[3]);
-            }
-            uint4 l;
-            if (B) { // values 0x00 / 0x01 / 0xFF: empty <=> bit 0 clear
-                l = make_uint4(~o.x & 0x01010101u, ~o.y & 0x01010101u, ~o.z & 0x01010101u, ~o.w & 0x01010101u);
-            } else { // values 0 / 1 / 2: empty <=> bit 1 set
-                l = make_uint4((o.x >> 1) & 0x01010101u, (o.y >> 1) & 0x01010101u, (o.z >> 1) & 0x01010101u,
-                               (o.w >> 1) & 0x01010101u);
-            }
-            if (vec_ok && byte0 + 16 <= live_bytes) {
-                if (obs) *reinterpret_cast<uint4 *>(obs + byte0) = o;
-                if (legal) *reinterpret_cast<uint4 *>(legal + byte0) = l;
-            } else if (byte0 < live_bytes) {
-                const u32 ow[4] = {o.x, o.y, o.z, o.w}, lw[4] = {l.x, l.y, l.z, l.w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (byte0 + k < live_bytes) {
-                        if (obs) obs[byte0 + k] = (signed char)((ow[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-                        if (legal) legal[byte0 + k] = (unsigned char)((lw[k >> 2] >> ((k & 3) * 8)) & 0xffu);
-                    }
-            }
+        if (!(vec_ok && nlive == BPW)) {
+            emit_slow(lds, view1, obs, legal, nlive * C, lane);
+        } else if (obs && legal) {
+            emit_fast<true, true>(lds, view1, obs, legal, lane);
+        } else if (obs) {
+            emit_fast<true, false>(lds, view1, obs, legal, lane);
+        } else {
+            emit_fast<false, true>(lds, view1, obs, legal, lane);
         }
     }
 };
 
 // fast state in HBM, per block of 64 boards: [LDS image][REGW x 64 words]
-template <int N, int ENC> struct FastState {
-    using L = Lpb<N, ENC>;
+template <int N, int ENC, int BPW> struct FastState {
+    using L = Lpb<N, ENC, BPW>;
     static constexpr int REGW = Regs<N>::REGW;
     static constexpr size_t BLOCK_BYTES = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
 };
 
-template <int N, int ENC, int MODE>
+template <int N, int ENC, int MODE, int BPW>
 __global__ __launch_bounds__(64) void k_lpb(KArgs a)
 {
-    using L = Lpb<N, ENC>;
-    using G = Geo<N>;
+    using L = Lpb<N, ENC, BPW>;
+    using G = Geo<N, BPW>;
     using LS = typename L::LS;
     constexpr bool B = ENC == 1;
     constexpr int C = G::C, JW = G::JW;
-    constexpr int REGW = Regs<N>::REGW;
     __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES];
 
     const int lane = (int)threadIdx.x;
     const int nb = (int)gridDim.x, bi = (int)blockIdx.x;
     const int blk = (nb & 7) == 0 ? (bi & 7) * (nb >> 3) + (bi >> 3) : bi; // contiguous env ranges per XCD
-    const int e0 = blk * 64;
+    const int e0 = blk * BPW;
     const int env = e0 + lane;
-    const bool live = env < a.E;
-    const int nlive = min(64, a.E - e0);
-    unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC>::BLOCK_BYTES;
+    const bool live = lane < BPW && env < a.E;
+    const int nlive = min(BPW, a.E - e0);
+    unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC, BPW>::BLOCK_BYTES;
     u32 *rblk = reinterpret_cast<u32 *>(sblk + L::LDS_BYTES);
     const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
     const bool selfplay = !two;
@@ -529,39 +595,39 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
 }
 
 // ---- cold kernels on the fast state ----
-template <int N, int ENC>
+template <int N, int ENC, int BPW>
 __global__ void k_lpb_get_state(const unsigned char *fast, int E, signed char *board, unsigned char *cur)
 {
-    using L = Lpb<N, ENC>;
-    constexpr int C = Geo<N>::C;
+    using L = Lpb<N, ENC, BPW>;
+    constexpr int C = Geo<N, BPW>::C;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)E * (C + 1)) return;
     const int env = (int)(gid / (C + 1)), r = (int)(gid - (long long)env * (C + 1));
-    const int blk = env >> 6, lane = env & 63;
-    const unsigned char *sblk = fast + (size_t)blk * FastState<N, ENC>::BLOCK_BYTES;
-    const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N>::JW * 64;
+    const int blk = env / BPW, lane = env % BPW;
+    const unsigned char *sblk = fast + (size_t)blk * FastState<N, ENC, BPW>::BLOCK_BYTES;
+    const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
     const int c = (int)(regs[3 * 64 + lane] & 1u);
     if (r < C) {
         if (board) {
             const int v = (ENC == 1 && c) ? 1 : 0;
-            board[(size_t)env * C + r] = (signed char)sblk[L::IMG + v * Geo<N>::IMG_BYTES + lane * C + r];
+            board[(size_t)env * C + r] = (signed char)sblk[L::IMG + v * Geo<N, BPW>::IMG_BYTES + lane * C + r];
         }
     } else if (cur) {
         cur[env] = (unsigned char)c;
     }
 }
 
-template <int N, int ENC>
+template <int N, int ENC, int BPW>
 __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsigned char *agents)
 {
-    using L = Lpb<N, ENC>;
+    using L = Lpb<N, ENC, BPW>;
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < E; i += blockDim.x) {
-        const unsigned char *sblk = fast + (size_t)(i >> 6) * FastState<N, ENC>::BLOCK_BYTES;
-        const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N>::JW * 64;
-        for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i & 63)];
-        if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i & 63)] >> 3) & 1u);
+        const unsigned char *sblk = fast + (size_t)(i / BPW) * FastState<N, ENC, BPW>::BLOCK_BYTES;
+        const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
+        for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i % BPW)];
+        if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i % BPW)] >> 3) & 1u);
     }
     for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
     __syncthreads();
@@ -574,4 +640,76 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
 }
 
 } // namespace lpb
+
+// ---- launchers of this translation unit ----
+#define HV_LPB_SIZES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
+
+template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
+{
+    const int blocks = (a.E + HV_BPW - 1) / HV_BPW;
+    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW>), dim3(blocks), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+template <int N, int ENC> static hipError_t lpb_launch_mode(int mode, const KArgs &a, hipStream_t st)
+{
+    switch (mode) {
+    case M_ROLLOUT2: return lpb_launch1<N, ENC, M_ROLLOUT2>(a, st);
+    case M_STEP: return lpb_launch1<N, ENC, M_STEP>(a, st);
+    case M_ROLLOUT1: return lpb_launch1<N, ENC, M_ROLLOUT1>(a, st);
+    case M_RESET: return lpb_launch1<N, ENC, M_RESET>(a, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t HV_LPB_NAME(launch)(int N, int enc, int mode, const KArgs &a, hipStream_t st)
+{
+    switch (N) {
+#define HV_CASE(n) case n: return enc ? lpb_launch_mode<n, 1>(mode, a, st) : lpb_launch_mode<n, 0>(mode, a, st);
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+size_t HV_LPB_NAME(block_bytes)(int N, int enc)
+{
+    switch (N) {
+#define HV_CASE(n) \
+    case n: return enc ? lpb::FastState<n, 1, HV_BPW>::BLOCK_BYTES : lpb::FastState<n, 0, HV_BPW>::BLOCK_BYTES;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return 0;
+    }
+}
+hipError_t HV_LPB_NAME(get_state)(const unsigned char *fast, int N, int enc, int E, signed char *board,
+                                  unsigned char *cur, hipStream_t st)
+{
+    const long long total = (long long)E * (N * N + 1);
+    const dim3 g((unsigned)((total + 255) / 256)), b(256);
+    switch (N) {
+#define HV_CASE(n)                                                                                          \
+    case n:                                                                                                 \
+        if (enc) hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 1, HV_BPW>), g, b, 0, st, fast, E, board, cur); \
+        else hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 0, HV_BPW>), g, b, 0, st, fast, E, board, cur);     \
+        break;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int E, double *out4,
+                              unsigned char *agents, hipStream_t st)
+{
+    switch (N) {
+#define HV_CASE(n)                                                                                                  \
+    case n:                                                                                                         \
+        if (enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW>), dim3(1), dim3(256), 0, st, fast, E, out4, agents); \
+        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0, HV_BPW>), dim3(1), dim3(256), 0, st, fast, E, out4, agents);     \
+        break;
+        HV_LPB_SIZES(HV_CASE)
+#undef HV_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 } // namespace hv
