@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libhexvec.so")
+SO_PATH = os.environ.get("HEXVEC_SO") or os.path.join(CSRC, "libhexvec.so")  # HEXVEC_SO: A/B experiments
 
 # create flags (include/hexvec.h)
 F_ENC_B = 0x1

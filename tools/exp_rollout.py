@@ -31,9 +31,11 @@ for two in (True, False):
                 reward=torch.empty((T, E), dtype=torch.float32, device=dev),
                 done=torch.empty((T, E), dtype=torch.uint8, device=dev))
     fn = env.rollout_random if two else env.rollout_selfplay
-    for rnd in range(3):
-      for name, out in (("all", full), ("none", {}), ("obs-only", {"obs": full["obs"]}),
-                      ("scalars", {k: full[k] for k in ("actions", "reward", "done")})):
+    for rnd in range(int(os.environ.get("ROUNDS", 3))):
+      for name, out in (("all", full), ("none", {})):
         ms = timeit(lambda: fn(T, out))
-        print("%s bpw=%s %-9s %.3f ms/launch  %.2f G units/s" % ("W2" if two else "W1", os.environ.get("HEXVEC_BPW", "auto"), name, ms, E * T / ms / 1e6))
+        print(os.path.basename(os.environ.get("HEXVEC_SO", "libhexvec.so")), "%s bpw=%s %-9s %.3f ms/launch  %.2f G units/s" % ("W2" if two else "W1", os.environ.get("HEXVEC_BPW", "auto"), name, ms, E * T / ms / 1e6))
+    if not two:
+        ms = timeit(lambda: env.step(), n=300)
+        print(os.path.basename(os.environ.get("HEXVEC_SO", "libhexvec.so")), "host-stepped step: %.2f us/step  %.2f G steps/s" % (ms * 1e3, E / ms / 1e6))
     env.close()
