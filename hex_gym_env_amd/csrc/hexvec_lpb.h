@@ -174,8 +174,9 @@ template <int N, int ENC, int BPW> struct Lpb {
 
     // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
     // true iff p now connects its two edges (HexGame.py:98-105 via connectivity).
-    static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int lane)
-    {
+    static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int y, int x,
+                                                 int lane)
+    { // (y, x): coordinates of the stone in p's own frame
         clear_bit(s.E0, idx0);
         clear_bit(s.E1, idx1);
         s.n_empty -= 1;
@@ -188,7 +189,6 @@ template <int N, int ENC, int BPW> struct Lpb {
         // union-find in p's own frame
         unsigned char *uf = lds + (p * BPW + lane) * PS;
         const int a = p ? idx1 : idx0;
-        const int y = a / N, x = a - y * N;
         const bool up = y > 0, dn = y < N - 1, lf = x > 0, rt = x < N - 1;
         int nb[6];
         nb[0] = up ? a - N : G::DUMMY;
@@ -443,13 +443,16 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
 
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: FT order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
-    auto ply = [&](int act, int fr) -> int {
-        const bool inb = (unsigned)act < (unsigned)C;
-        const int at = inb ? L::transpose(act) : 0;
-        const int idx0 = fr ? at : act, idx1 = fr ? act : at;
-        if (!inb || !L::test_bit(s.E0, idx0)) return 3;
+    // check = false for actions the library drew itself (always legal).
+    auto ply = [&](int act, int fr, bool check) -> int {
+        const bool inb = !check || (unsigned)act < (unsigned)C;
+        const int yf = inb ? act / N : 0, xf = inb ? act - yf * N : 0;
+        const int at = xf * N + yf;
+        const int idx0 = fr ? at : (inb ? act : 0), idx1 = fr ? (inb ? act : 0) : at;
+        if (check && (!inb || !L::test_bit(s.E0, idx0))) return 3;
         const int p = s.cur;
-        const bool win = L::place(lds, s, idx0, idx1, p, lane);
+        const bool same = p == fr; // the plane of colour p is indexed in p's own frame
+        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane);
         int ret = -1;
         if (win) {
             s.done = 1;
@@ -461,9 +464,9 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         return ret;
     };
     // env B HexEnv.step (HexSingleGame.py:233-263) on top of ply(); returns reward[0]
-    auto envb_step = [&](int act) -> int {
+    auto envb_step = [&](int act, bool check) -> int {
         const int mover = s.cur;
-        const int w = ply(act, mover);
+        const int w = ply(act, mover, check);
         s.winner = w;
         int r = 0;
         if (w == 3) {
@@ -474,17 +477,26 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         }
         return mover == 0 ? r : -r;
     };
-    // the opponent's reply in self-play handles; returns reward[0] (B) / nothing used (A)
-    auto reset_lane = [&]() {
-        L::fresh_regs(s, first);
+    // a ply of the in-env opponent: the reply inside step, or the opening after a reset
+    // (SelfplayWrapper.py:79-80 / :187-190, HexGame.py:224-230 / :259-265); returns reward[0] (B)
+    auto opponent_ply = [&](int oa, bool check) -> int {
+        if (B) return envb_step(oa, check);
+        s.winner = ply(oa, 1, check); // hex-v0: the opponent's view is the transposed frame
+        return 0;
     };
-    auto opening = [&](const int *opp) { // the opponent opens (SelfplayWrapper.py:79-80 / HexGame.py:224-230)
-        if (B) {
-            const int oa = opp ? opp[env] : L::rng_action(s, s.cur);
-            envb_step(oa);
-        } else {
-            const int oa = opp ? opp[env] : L::rng_action(s, 1);
-            s.winner = ply(oa, 1);
+    const bool opens = selfplay && (B ? s.agent != 0 : first != 0); // the opponent moves first after a reset
+    // wave-level: finished boards -> terminal obs, statistics, fresh board.  `won` per lane.
+    auto handle_done = [&](bool dn, int won, signed char *tobs_row) {
+        const u64 dmask = __ballot(dn);
+        if (!dmask) return;
+        if (tobs_row) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, tobs_row, lane);
+        L::clear_boards(lds, dmask, lane);
+        if (dn) {
+            s.sr += s.ep_ret;
+            s.sl += s.ep_len;
+            s.se += 1;
+            s.sw += won;
+            L::fresh_regs(s, first);
         }
     };
 
@@ -494,79 +506,90 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
         if (!a.init) L::clear_boards(lds, __ballot(sel), lane);
         if (sel) {
-            reset_lane();
-            const bool opens = selfplay && (B ? s.agent != 0 : first != 0);
-            if (opens) opening(a.opp_actions);
+            L::fresh_regs(s, first);
+            if (opens) opponent_ply(a.opp_actions ? a.opp_actions[env] : L::rng_action(s, B ? s.cur : 1),
+                                    a.opp_actions != nullptr);
         }
         L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
                 a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
     } else {
+        const bool ext_a = MODE == M_STEP && a.actions, ext_o = MODE == M_STEP && a.opp_actions;
         for (int t = 0; t < a.T; ++t) {
             const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
             const size_t o = ob + (size_t)lane;
+            signed char *tobs_row = a.tobs ? a.tobs + ob * C : nullptr;
             if (MODE == M_ROLLOUT2)
                 L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
                         a.legal ? a.legal + ob * C : nullptr, nlive, vec_ok, lane);
-            int act = 0, rew = 0, won = 0;
+            // ---- slot 1: the agent's ply (two-sided: the mover's)
+            int act = 0, rew = 0, won = 0, f_done = 0, f_winner = -1;
+            bool reply = false; // this lane still owes the opponent's reply
             if (live) {
-                // the mover's own frame in B; absolute (F) coordinates in A
-                act = (MODE == M_STEP && a.actions) ? a.actions[o] : L::rng_action(s, B ? s.cur : 0);
+                act = ext_a ? a.actions[o] : L::rng_action(s, B ? s.cur : 0); // B: the mover's frame
                 if (two) {
-                    if (B) {
-                        const int mover = s.cur;
-                        const int rb = envb_step(act);
+                    const int mover = s.cur;
+                    if (B) { // HexEnv.step (HexSingleGame.py:233-263)
+                        const int rb = envb_step(act, ext_a);
                         rew = mover == 0 ? rb : -rb;
                         s.ep_ret += rb;
                         won = s.done && s.winner == 0;
-                    } else {
-                        const int mover = s.cur;
-                        const int w = ply(act, 0);
+                    } else { // HexGame.make_move with hex-v0's convention for an illegal ply
+                        const int w = ply(act, 0, ext_a);
                         s.winner = w;
                         if (w == 3) s.done = 1;
                         rew = w == mover ? 1 : (w == 3 ? -100 : 0);
                         s.ep_ret += w == 0 ? 1 : (w == 1 ? -1 : 0);
                         won = s.done && w == 0;
                     }
-                } else if (B) { // SelfPlayEnv.step (SelfplayWrapper.py:174-199)
-                    int rb = envb_step(act);
-                    if (!s.done) {
-                        const int oa = (MODE == M_STEP && a.opp_actions) ? a.opp_actions[o] : L::rng_action(s, s.cur);
-                        rb = envb_step(oa);
-                    }
+                } else if (B) { // SelfPlayEnv.step (SelfplayWrapper.py:174-199), first half
+                    const int rb = envb_step(act, ext_a);
                     rew = s.agent == 0 ? rb : -rb;
-                    s.ep_ret += rew;
-                    won = s.done && rew > 0;
-                } else { // hex-v0 HexEnv.step (HexGame.py:244-295), agent BLACK
-                    s.winner = ply(act, 0);
+                    reply = !s.done;
+                } else { // hex-v0 HexEnv.step (HexGame.py:244-295), agent BLACK, first half
+                    s.winner = ply(act, 0, ext_a);
                     if (s.winner == 3) s.done = 1;
-                    if (!s.done) {
-                        const int oa = (MODE == M_STEP && a.opp_actions) ? a.opp_actions[o] : L::rng_action(s, 1);
-                        s.winner = ply(oa, 1);
+                    rew = s.winner == 0 ? 1 : (s.winner == 3 ? -100 : 0);
+                    reply = !s.done;
+                }
+                if (!reply) { // the step's result is final for this lane
+                    if (!two) {
+                        s.ep_ret += rew;
+                        won = s.done && rew > 0;
                     }
-                    rew = s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0));
-                    s.ep_ret += rew;
-                    won = s.done && rew > 0;
+                    s.ep_len += 1;
+                    f_done = s.done;
+                    f_winner = s.winner;
                 }
-                s.ep_len += 1;
-                if (a.reward) a.reward[o] = (float)rew;
-                if (a.done) a.done[o] = (unsigned char)s.done;
-                if (a.winner) a.winner[o] = (signed char)s.winner;
-                if (a.actions_out) a.actions_out[o] = act;
             }
-            const bool dn = live && s.done;
-            const u64 dmask = __ballot(dn);
-            if (dmask) {
-                if (a.tobs) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, a.tobs + ob * C, lane);
-                L::clear_boards(lds, dmask, lane);
-                if (dn) {
-                    s.sr += s.ep_ret;
-                    s.sl += s.ep_len;
-                    s.se += 1;
-                    s.sw += won;
-                    reset_lane();
-                    const bool opens = selfplay && (B ? s.agent != 0 : first != 0);
-                    if (opens) opening(nullptr);
+            const bool dn1 = live && !reply && s.done;
+            handle_done(dn1, won, tobs_row);
+            // ---- slot 2: the opponent's reply, or its opening on the boards just reset
+            if (selfplay) {
+                const bool open2 = dn1 && opens;
+                if (reply || open2) {
+                    const bool ext = reply && ext_o;
+                    const int oa = ext ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
+                    const int rb = opponent_ply(oa, ext);
+                    if (reply) {
+                        rew = B ? (s.agent == 0 ? rb : -rb)
+                                : (s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0)));
+                        s.ep_ret += rew;
+                        s.ep_len += 1;
+                        won = s.done && rew > 0;
+                        f_done = s.done;
+                        f_winner = s.winner;
+                    }
                 }
+                const bool dn2 = reply && s.done;
+                handle_done(dn2, won, tobs_row);
+                // ---- slot 3: openings of the boards that ended on the reply
+                if (dn2 && opens) opponent_ply(L::rng_action(s, B ? s.cur : 1), false);
+            }
+            if (live) {
+                if (a.reward) a.reward[o] = (float)rew;
+                if (a.done) a.done[o] = (unsigned char)f_done;
+                if (a.winner) a.winner[o] = (signed char)f_winner;
+                if (a.actions_out) a.actions_out[o] = act;
             }
             if (MODE != M_ROLLOUT2)
                 L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
