@@ -24,7 +24,8 @@ F_EXACT_LABELS = 0x40
 MIN_BOARD, MAX_BOARD = 2, 14
 
 SYMBOLS = [
-    "hexvec_create", "hexvec_destroy", "hexvec_reset", "hexvec_step", "hexvec_apply_moves",
+    "hexvec_create", "hexvec_destroy", "hexvec_reset", "hexvec_step", "hexvec_step_agent",
+    "hexvec_step_opponent", "hexvec_apply_moves",
     "hexvec_rollout_random", "hexvec_rollout_selfplay", "hexvec_get_state", "hexvec_set_state",
     "hexvec_episode_stats", "hexvec_agent_colours", "hexvec_board_size", "hexvec_num_envs",
     "hexvec_flags", "hexvec_last_kernel", "hexvec_last_error",
@@ -63,6 +64,8 @@ def lib():
     L.hexvec_destroy.argtypes = [vp]
     L.hexvec_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     L.hexvec_step.argtypes = [vp] + [vp] * 9
+    L.hexvec_step_agent.argtypes = [vp] + [vp] * 9
+    L.hexvec_step_opponent.argtypes = [vp] + [vp] * 9
     L.hexvec_apply_moves.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.hexvec_rollout_random.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.hexvec_rollout_selfplay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]

@@ -203,6 +203,46 @@ extern "C" int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *o
     return hv::run(h, hv::M_STEP, a, stream);
 }
 
+extern "C" int hexvec_step_agent(hexvec_t *h, const int32_t *actions, int8_t *obs, uint8_t *legal,
+                                 float *reward, uint8_t *done, int8_t *winner, int8_t *terminal_obs,
+                                 uint8_t *pending, void *stream)
+{
+    HV_HANDLE(h);
+    if (!h->fast_mode || (h->flags & HEXVEC_F_TWO_SIDED))
+        return fail(HEXVEC_E_MODE, "%s", "the split step needs an auto-reset self-play handle");
+    hv::KArgs a = hv::base_args(h);
+    a.phase = 1;
+    a.actions = actions;
+    a.obs = (signed char *)obs;
+    a.legal = legal;
+    a.reward = reward;
+    a.done = done;
+    a.winner = (signed char *)winner;
+    a.tobs = (signed char *)terminal_obs;
+    a.pending = pending;
+    return hv::run(h, hv::M_STEP, a, stream);
+}
+
+extern "C" int hexvec_step_opponent(hexvec_t *h, const int32_t *opp_actions, int8_t *obs, uint8_t *legal,
+                                    float *reward, uint8_t *done, int8_t *winner, int8_t *terminal_obs,
+                                    uint8_t *pending, void *stream)
+{
+    HV_HANDLE(h);
+    if (!h->fast_mode || (h->flags & HEXVEC_F_TWO_SIDED))
+        return fail(HEXVEC_E_MODE, "%s", "the split step needs an auto-reset self-play handle");
+    hv::KArgs a = hv::base_args(h);
+    a.phase = 2;
+    a.opp_actions = opp_actions;
+    a.obs = (signed char *)obs;
+    a.legal = legal;
+    a.reward = reward;
+    a.done = done;
+    a.winner = (signed char *)winner;
+    a.tobs = (signed char *)terminal_obs;
+    a.pending = pending;
+    return hv::run(h, hv::M_STEP, a, stream);
+}
+
 extern "C" int hexvec_apply_moves(hexvec_t *h, const int32_t *actions, int T, int8_t *ret_out,
                                   uint8_t *done_out, int8_t *r_black_out, uint8_t *legal_out,
                                   int8_t *obs_out, void *stream)

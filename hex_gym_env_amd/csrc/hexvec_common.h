@@ -42,6 +42,8 @@ struct KArgs {
     const signed char *board_in;   // M_SETSTATE
     const unsigned char *labels_in; // M_SETSTATE (optional)
     int cur_in;
+    int phase;              // M_STEP on self-play handles: 0 whole step, 1 agent ply only, 2 opponent plies only
+    unsigned char *pending; // split step: 1 = reply owed, 2 = opening owed
 };
 
 // ------------------------------------------------------------------ helpers

@@ -80,6 +80,7 @@ template <int N, int ENC, int BPW> struct Lpb {
         int winner;
         int n_empty;
         int agent;
+        int pend; // split step: 0 agent to move, 1 the opponent owes its reply, 2 its opening
         u32 ctr, key;
         int ep_ret, ep_len;
         int sr, sl, se, sw;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         s.agent = !B ? 0 : (a.flags & HEXVEC_F_AGENT_RANDOM) ? (int)(mix32(s.key ^ 0xA5A5A5A5U) & 1u)
                   : (a.flags & HEXVEC_F_AGENT_WHITE) ? 1 : 0;
         s.sr = s.sl = s.se = s.sw = 0;
+        s.pend = 0;
         L::fresh_regs(s, first);
     } else {
         for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
@@ -435,6 +437,7 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         s.agent = (fl >> 3) & 1;
         s.winner = (int)((fl >> 4) & 7) - 1;
         s.n_empty = (int)(fl >> 8) & 0xff;
+        s.pend = (int)(fl >> 16) & 3;
         s.sr = (int)r[4 * 64 + lane];
         s.sl = (int)r[5 * 64 + lane];
         s.se = (int)r[6 * 64 + lane];
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
         const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
         if (!a.init) L::clear_boards(lds, __ballot(sel), lane);
         if (sel) {
+            s.pend = 0;
             L::fresh_regs(s, first);
             if (opens) opponent_ply(a.opp_actions ? a.opp_actions[env] : L::rng_action(s, B ? s.cur : 1),
                                     a.opp_actions != nullptr);
@@ -514,6 +518,55 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
                 a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
     } else {
         const bool ext_a = MODE == M_STEP && a.actions, ext_o = MODE == M_STEP && a.opp_actions;
+        if (MODE == M_STEP && a.phase != 0) {
+            // Split step for opponents that are policies on the device: the same slots as below,
+            // one launch per slot, with the opponent's actions supplied by the caller.
+            const size_t o = (size_t)env;
+            signed char *tobs_row = a.tobs ? a.tobs + (size_t)e0 * C : nullptr;
+            int rew = 0, won = 0;
+            bool fin = false; // the env step completed in this call
+            if (a.phase == 1) { // the agent's ply (slot 1)
+                if (live && s.pend == 0) {
+                    const int act = ext_a ? a.actions[o] : L::rng_action(s, B ? s.cur : 0);
+                    if (B) {
+                        const int rb = envb_step(act, ext_a);
+                        rew = s.agent == 0 ? rb : -rb;
+                    } else {
+                        s.winner = ply(act, 0, ext_a);
+                        if (s.winner == 3) s.done = 1;
+                        rew = s.winner == 0 ? 1 : (s.winner == 3 ? -100 : 0);
+                    }
+                    fin = s.done != 0;
+                    s.pend = fin ? 0 : 1;
+                }
+            } else { // the opponent's plies: replies (slot 2) and openings (slot 3)
+                const int was = s.pend;
+                if (live && was != 0) {
+                    const int oa = ext_o ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
+                    const int rb = opponent_ply(oa, ext_o);
+                    s.pend = 0;
+                    if (was == 1) {
+                        rew = B ? (s.agent == 0 ? rb : -rb)
+                                : (s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0)));
+                        fin = true;
+                    }
+                }
+            }
+            if (fin) {
+                s.ep_ret += rew;
+                s.ep_len += 1;
+                won = s.done && rew > 0;
+                if (a.reward) a.reward[o] = (float)rew;
+                if (a.done) a.done[o] = (unsigned char)s.done;
+                if (a.winner) a.winner[o] = (signed char)s.winner;
+            }
+            const bool dn = fin && s.done;
+            handle_done(dn, won, tobs_row);
+            if (dn && opens) s.pend = 2; // the opponent opens on the fresh board
+            if (live && a.pending) a.pending[o] = (unsigned char)s.pend;
+            L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                    a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+        } else
         for (int t = 0; t < a.T; ++t) {
             const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
             const size_t o = ob + (size_t)lane;
@@ -610,7 +663,7 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
     r[1 * 64 + lane] = (u32)s.ep_ret;
     r[2 * 64 + lane] = (u32)s.ep_len;
     r[3 * 64 + lane] = (u32)s.cur | ((u32)s.done << 2) | ((u32)s.agent << 3) | ((u32)(s.winner + 1) << 4) |
-                       ((u32)(s.n_empty & 0xff) << 8);
+                       ((u32)(s.n_empty & 0xff) << 8) | ((u32)s.pend << 16);
     r[4 * 64 + lane] = (u32)s.sr;
     r[5 * 64 + lane] = (u32)s.sl;
     r[6 * 64 + lane] = (u32)s.se;

@@ -77,6 +77,7 @@ class HexVecEnv:
         self.reward = torch.empty(E, dtype=torch.float32, device=dev)
         self.done = torch.empty(E, dtype=torch.uint8, device=dev)
         self.winner = torch.empty(E, dtype=torch.int8, device=dev)
+        self.pending = torch.zeros(E, dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -133,6 +134,28 @@ class HexVecEnv:
                                        _p(self.reward), _p(self.done), _p(self.winner),
                                        _p(terminal_obs), self._stream()))
         return self.obs, self.reward, self.done, self.legal, self.winner
+
+    def step_agent(self, actions=None, terminal_obs=None):
+        """Split step, first half: the agent's ply only -> (obs, legal, pending).
+
+        Boards with pending == 1 show the OPPONENT's view; feed them to the opponent policy and
+        call step_opponent() until pending is all zero (a second call plays the openings of boards
+        that were reset with the opponent to move first).  reward / done / winner are complete
+        after the last call."""
+        a = self._i32(actions, (self.num_envs,))
+        _lib.check(self._L.hexvec_step_agent(self._h, _p(a), _p(self.obs), _p(self.legal),
+                                             _p(self.reward), _p(self.done), _p(self.winner),
+                                             _p(terminal_obs), _p(self.pending), self._stream()))
+        return self.obs, self.legal, self.pending
+
+    def step_opponent(self, opp_actions=None, terminal_obs=None):
+        """Split step, second half: the opponent's ply on every pending board
+        -> (obs, reward, done, legal, winner, pending)."""
+        o = self._i32(opp_actions, (self.num_envs,))
+        _lib.check(self._L.hexvec_step_opponent(self._h, _p(o), _p(self.obs), _p(self.legal),
+                                                _p(self.reward), _p(self.done), _p(self.winner),
+                                                _p(terminal_obs), _p(self.pending), self._stream()))
+        return self.obs, self.reward, self.done, self.legal, self.winner, self.pending
 
     def apply_moves(self, actions):
         """Literal plies (no reset) from actions [T,E] -> ret, done, r_black, legal, obs (after each ply)."""

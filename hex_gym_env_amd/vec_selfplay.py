@@ -1,0 +1,224 @@
+"""VecSelfPlayEnv: the SelfplayWrapper semantics for thousands of boards, opponents on the device.
+
+The reference's SelfPlayEnv (minihex/SelfplayWrapper.py:37-208) keeps a buffer of opponent
+policies, picks one per episode (80 % the best model, 20 % uniformly from the buffer,
+:97-104; in eval mode the buffer is walked in order, :92-96) and lets it answer every agent
+ply.  Here every board has its own opponent slot; one env step is
+
+    step_agent(actions)  ->  [ group pending boards by slot -> policy(obs, mask) ]  ->  step_opponent(...)
+
+repeated while boards are pending (a second round plays the openings of boards that were reset
+with the opponent to move first).  All tensors stay on the GPU.
+
+Policies are objects with  choose_actions(obs int8 [B,N,N], legal uint8 [B,N*N]) -> int64 [B]
+(the batched form of OpponentPolicy.choose_action(board, action_mask), :26-35):
+RandomLegalPolicy (BaseRandomPolicy, :16-24) and MlpActorPolicy (an SB3 MaskablePPO "MlpPolicy"
+actor, loadable from the reference's shipped checkpoints with weights_only=True).
+"""
+import io
+import zipfile
+
+import numpy as np
+import torch
+
+from .vec_env import HexVecEnv
+
+__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "VecSelfPlayEnv"]
+
+
+class RandomLegalPolicy:
+    """uniform over the empty cells, drawn with torch's generator on the device"""
+
+    def __init__(self, generator=None):
+        self.generator = generator
+
+    def choose_actions(self, obs, legal):
+        return torch.multinomial(legal.float(), 1, generator=self.generator).squeeze(1)
+
+    def save_model(self, path):
+        return None
+
+
+class MlpActorPolicy(torch.nn.Module):
+    """The actor of sb3_contrib's MaskableActorCriticPolicy with the default MLP extractor:
+    flatten -> float -> Linear-Tanh-Linear-Tanh (mlp_extractor.policy_net) -> Linear (action_net)
+    -> logits, illegal actions masked out, categorical sample (or argmax)."""
+
+    def __init__(self, n_cells, hidden=(64, 64), deterministic=False, generator=None):
+        super().__init__()
+        dims = [n_cells] + list(hidden)
+        layers = []
+        for a, b in zip(dims, dims[1:]):
+            layers += [torch.nn.Linear(a, b), torch.nn.Tanh()]
+        self.policy_net = torch.nn.Sequential(*layers)
+        self.action_net = torch.nn.Linear(dims[-1], n_cells)
+        self.deterministic = deterministic
+        self.generator = generator
+
+    @classmethod
+    def from_state_dict(cls, sd, **kw):
+        ws = sorted(k for k in sd if k.startswith("mlp_extractor.policy_net.") and k.endswith(".weight"))
+        hidden = [int(sd[k].shape[0]) for k in ws]
+        pol = cls(int(sd[ws[0]].shape[1]), hidden, **kw)
+        lin = [m for m in pol.policy_net if isinstance(m, torch.nn.Linear)]
+        with torch.no_grad():
+            for m, k in zip(lin, ws):
+                m.weight.copy_(torch.as_tensor(sd[k]))
+                m.bias.copy_(torch.as_tensor(sd[k[:-6] + "bias"]))
+            pol.action_net.weight.copy_(torch.as_tensor(sd["action_net.weight"]))
+            pol.action_net.bias.copy_(torch.as_tensor(sd["action_net.bias"]))
+        return pol
+
+    @classmethod
+    def from_sb3_zip(cls, path, **kw):
+        """policy.pth of an SB3 model zip; loaded with weights_only=True (nothing is executed)"""
+        with zipfile.ZipFile(path) as z:
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+        return cls.from_state_dict(sd, **kw)
+
+    @classmethod
+    def from_npz(cls, path, **kw):
+        d = np.load(path)
+        return cls.from_state_dict({k: d[k] for k in d.files}, **kw)
+
+    @torch.no_grad()
+    def logits(self, obs, legal):
+        x = obs.reshape(obs.shape[0], -1).float()
+        z = self.action_net(self.policy_net(x))
+        return z.masked_fill(legal == 0, float("-inf"))
+
+    @torch.no_grad()
+    def choose_actions(self, obs, legal):
+        z = self.logits(obs, legal)
+        if self.deterministic:
+            return z.argmax(1)
+        return torch.multinomial(torch.softmax(z, 1), 1, generator=self.generator).squeeze(1)
+
+    def save_model(self, path):
+        torch.save(self.state_dict(), path)
+
+
+class VecSelfPlayEnv:
+    """selfplay_wrapper(HexEnv)(board_size, buffer_size, scores, ...) for num_envs boards."""
+
+    def __init__(self, board_size=5, num_envs=1024, buffer_size=20, scores=None, base_model=None,
+                 agent_player_num=None, seed=0, device=None, prob_best=0.8):
+        self.vec = HexVecEnv(board_size, num_envs, device=device, seed=seed, encoding="B",
+                             agent_player_num=agent_player_num)
+        self.device, self.num_envs, self.board_size = self.vec.device, num_envs, board_size
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(int(seed) + 0x5EED)
+        if base_model is None:           # SelfplayWrapper.py:58-60
+            self.opponent_models = [RandomLegalPolicy(self._gen) for _ in range(buffer_size)]
+            self.opponent_scores = np.zeros(buffer_size)
+            self.best_model = RandomLegalPolicy(self._gen)
+        else:                            # :54-57
+            self.opponent_models = [base_model for _ in range(buffer_size)]
+            self.opponent_scores = np.zeros(buffer_size) if scores is None else np.asarray(scores, float)
+            self.best_model = base_model
+        self.best_score = float(np.max(self.opponent_scores))
+        self.best_mean_reward = -np.inf
+        self.prob_best = prob_best
+        self.eval_state = False
+        self.eval_episode = 0
+        # opponent slot per board: -1 = best_model, k >= 0 = buffer slot k
+        self.slot = torch.full((num_envs,), -1, dtype=torch.long, device=self.device)
+        self._opp = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
+        self.terminal_obs = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8,
+                                        device=self.device)
+
+    # -- opponent selection (setup_opponents, :91-104) -----------------------
+    def _setup_opponents(self, idx):
+        n = int(idx.numel())
+        if n == 0:
+            return
+        if self.eval_state:              # walk the buffer in order, one slot per episode
+            k = (torch.arange(n, device=self.device) + self.eval_episode) % len(self.opponent_models)
+            self.eval_episode += n
+            self.slot[idx] = k
+            return
+        u = torch.rand(n, generator=self._gen, device=self.device)
+        k = torch.randint(len(self.opponent_models), (n,), generator=self._gen, device=self.device)
+        self.slot[idx] = torch.where(u < self.prob_best, torch.full_like(k, -1), k)
+
+    def _opponent_actions(self, obs, legal, pending):
+        idx_all = torch.nonzero(pending, as_tuple=False).squeeze(1)
+        if idx_all.numel() == 0:
+            return
+        slots = self.slot[idx_all]
+        for k in torch.unique(slots).tolist():
+            idx = idx_all[slots == k]
+            pol = self.best_model if k < 0 else self.opponent_models[k]
+            a = pol.choose_actions(obs[idx], legal[idx])
+            self._opp[idx] = a.to(torch.int32)
+
+    def _play_opponents(self, obs, legal, pending):
+        out = None
+        while bool(pending.any()):
+            opening = pending == 2       # fresh boards: pick their opponent first (:75 before :79-80)
+            if bool(opening.any()):
+                self._setup_opponents(torch.nonzero(opening, as_tuple=False).squeeze(1))
+            self._opponent_actions(obs, legal, pending)
+            out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+            obs, legal, pending = out[0], out[3], out[5]
+        return out
+
+    # -- gym-like API ----------------------------------------------------------
+    def reset(self):
+        """SelfPlayEnv.reset for every board (:69-89): new opponent, then it opens where the agent
+        is WHITE.  The opponent's view of the empty board is all zeros, so its opening is computed
+        up front and handed to hexvec_reset."""
+        every = torch.arange(self.num_envs, device=self.device)
+        self._setup_opponents(every)
+        n = self.board_size
+        empty = torch.zeros((self.num_envs, n, n), dtype=torch.int8, device=self.device)
+        full = torch.ones((self.num_envs, n * n), dtype=torch.uint8, device=self.device)
+        self._opponent_actions(empty, full, self.vec.agent_colours() != 0)
+        return self.vec.reset(opp_actions=self._opp)
+
+    def step(self, actions):
+        """actions int [E] (agent's view) -> obs, reward, done, legal, winner.
+
+        Finished boards are reset; their opponent is re-drawn before it opens (if it opens)."""
+        self.vec.done.zero_()        # the split calls write only the boards whose step completes
+        obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
+        ended1 = self.vec.done != 0
+        no_opening = ended1 & (pending == 0)         # BLACK agents: a new episode, a new opponent
+        if bool(no_opening.any()):
+            self._setup_opponents(torch.nonzero(no_opening, as_tuple=False).squeeze(1))
+        self._play_opponents(obs, legal, pending)     # replies; re-draw + openings inside
+        ended2 = (self.vec.done != 0) & ~ended1 & (self.vec.agent_colours() == 0)
+        if bool(ended2.any()):
+            self._setup_opponents(torch.nonzero(ended2, as_tuple=False).squeeze(1))
+        return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
+
+    def legal_actions(self):
+        return self.vec.legal
+
+    # -- buffer API (SelfplayWrapper.py:106-144) -------------------------------
+    def set_eval(self, eval_state):
+        self.eval_episode = 0
+        self.eval_state = bool(eval_state)
+        assert len(self.opponent_models) == len(self.opponent_scores)
+
+    def get_scores(self):
+        return self.opponent_scores
+
+    def get_opponent_models(self):
+        return self.opponent_models
+
+    def get_best_mean_reward(self):
+        return self.best_mean_reward
+
+    def set_opponent_model(self, index, model, score):
+        self.opponent_models[index] = model
+        self.opponent_scores[index] = score
+        if score > self.best_score:
+            self.best_model = model
+            self.best_score = score
+
+    def save_best_model(self, path=None):
+        self.best_model.save_model(path or ("models/best_model_" + str(self.best_score)))
+
+    def episode_stats(self):
+        return self.vec.episode_stats()

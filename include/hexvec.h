@@ -101,6 +101,27 @@ int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *opp_actions,
                 uint8_t *legal, float *reward, uint8_t *done, int8_t *winner,
                 int8_t *terminal_obs, void *stream);
 
+/* Split form of hexvec_step for opponents that are policies on the device (auto-reset
+ * self-play handles).  One env step =
+ *   hexvec_step_agent(actions)            the agent's ply; boards whose game goes on now show
+ *                                         the OPPONENT's view in obs/legal (what
+ *                                         OpponentPolicy.choose_action is given,
+ *                                         SelfplayWrapper.py:161) and get pending = 1;
+ *   hexvec_step_opponent(opp_actions)     the opponent's ply on every pending board.  Boards
+ *                                         that finish are reset; if the opponent opens on them
+ *                                         (SelfplayWrapper.py:79-80, HexGame.py:224-230) they
+ *                                         get pending = 2 and show the opponent's view again;
+ *   hexvec_step_opponent(opp_actions)     ... repeated until no board is pending.
+ * reward / done / winner / terminal_obs are written only for the boards whose step completes
+ * in that call, obs / legal / pending (uint8 [E]) for all boards.  actions / opp_actions may be
+ * NULL (uniform-legal RNG).  The result equals hexvec_step with the same actions. */
+int hexvec_step_agent(hexvec_t *h, const int32_t *actions, int8_t *obs, uint8_t *legal, float *reward,
+                      uint8_t *done, int8_t *winner, int8_t *terminal_obs, uint8_t *pending,
+                      void *stream);
+int hexvec_step_opponent(hexvec_t *h, const int32_t *opp_actions, int8_t *obs, uint8_t *legal,
+                         float *reward, uint8_t *done, int8_t *winner, int8_t *terminal_obs,
+                         uint8_t *pending, void *stream);
+
 /* Parity entry (TWO_SIDED handles): T literal plies from actions [T, E], never
  * resets, reproduces the reference on illegal plies and plies after the end.
  * enc A: HexGame.make_move HexGame.py:85-111; enc B: HexEnv.step HexSingleGame.py:233-263.

@@ -336,6 +336,18 @@ def gen_sample_board(HexEnvB, sizes):
     return out
 
 
+def export_actor_weights(zip_path, out_path):
+    """actor weights (data) of a shipped SB3 checkpoint -> npz; torch.load(weights_only=True)"""
+    import io
+    import zipfile
+    import torch
+    with zipfile.ZipFile(zip_path) as z:
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
+    keep = {k: v.numpy() for k, v in sd.items()
+            if k.startswith("mlp_extractor.policy_net.") or k.startswith("action_net.")}
+    np.savez_compressed(out_path, **keep)
+
+
 def gen_render(HexEnvA, playerA, HexEnvB, random_policy):
     texts = {}
     for n in (3, 5):
@@ -387,6 +399,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "preplaced.npz"),
                         **gen_preplaced(HexGameA, playerA, HexGameB, [3, 5, 7, 11], rng))
     np.savez_compressed(os.path.join(OUT, "sample_board.npz"), **gen_sample_board(HexEnvB, [5, 7, 11]))
+    export_actor_weights(os.path.join(REF, "models", "5x5_MLP-default_lr-0.0003_31"),
+                         os.path.join(OUT, "sb3_5x5_actor.npz"))
     for name, (board, text) in gen_render(HexEnvA, playerA, HexEnvB, random_policy).items():
         np.save(os.path.join(OUT, name + "_board.npy"), board)
         with open(os.path.join(OUT, name + ".txt"), "w") as f:
