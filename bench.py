@@ -66,12 +66,15 @@ def main():
     import torch
     import torch.distributed as dist
     import hex_gym_env_amd as hx
+    from hex_gym_env_amd import dist as hxdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if under_launcher:      # torch.distributed.run: one process per GPU, RCCL ("nccl" on ROCm)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -101,8 +104,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        hxdist.barrier()
         torch.cuda.synchronize(dev)
 
     run_steps(args.warmup)
@@ -116,10 +118,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1)        # HIP events around the timed launches
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = hxdist.max_over_ranks(dt, dev)
     value = world * E * args.steps / dt
 
     # the dominant kernel: bytes it must write per env step (obs + mask + action + reward + done)
@@ -182,11 +181,7 @@ def main():
                                "kernel": env2.last_kernel()}
 
     # episode statistics: the only cross-GPU exchange (logging), one all-gather over RCCL
-    stats = env.episode_stats()
-    if world > 1:
-        gathered = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        stats = torch.stack(gathered).sum(0)
+    per_rank, stats = hxdist.gather_episode_stats(env.episode_stats())
     stats = stats.cpu().tolist()
 
     if rank == 0:
@@ -214,7 +209,7 @@ def main():
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

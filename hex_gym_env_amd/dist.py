@@ -42,6 +42,20 @@ def gather_episode_stats(local_stats):
     return per, per.sum(0)
 
 
+def max_over_ranks(value, device=None):
+    """max of a python float over all ranks (the bench's timing rule); identity without a group"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
 def summarize(totals):
     t = [float(x) for x in totals]
     n = max(t[2], 1.0)
