@@ -18,6 +18,7 @@ struct hexvec {
     bool fast_mode;      // lane-per-board kernels + fast state (auto-reset handles)
     int bpw;             // boards per wavefront of the fast kernels (64 or 32)
     unsigned char *fast;
+    size_t fast_bytes;
 };
 
 static thread_local char g_err[512] = "";
@@ -136,6 +137,7 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
         const size_t bytes = h->bpw == 32
                                  ? (size_t)((num_envs + 31) / 32) * hv::lpb32_block_bytes(board_size, enc)
                                  : (size_t)((num_envs + 63) / 64) * hv::lpb64_block_bytes(board_size, enc);
+        h->fast_bytes = bytes;
         ok = hipMalloc(&h->fast, bytes) == hipSuccess;
     } else {
         ok = hipMalloc(&h->planes, E * hv::PLANE_WORDS * 4) == hipSuccess &&
@@ -375,6 +377,54 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
     }
     g_kernel = "k_agents";
     HV_HIP(hv::wpb_agents(h->hot, h->E, out, (hipStream_t)stream));
+    return HEXVEC_OK;
+}
+
+// ---- checkpoint of the env state (opaque, valid for a handle created with the same arguments) ----
+static size_t state_bytes(const hexvec *h)
+{
+    const size_t E = (size_t)h->E;
+    return h->fast_mode ? h->fast_bytes : E * (hv::PLANE_WORDS + hv::HOT_WORDS + hv::STAT_WORDS) * 4;
+}
+extern "C" size_t hexvec_state_bytes(const hexvec_t *h) { return h ? state_bytes(h) : 0; }
+
+extern "C" int hexvec_export_state(hexvec_t *h, void *dst, void *stream)
+{
+    HV_HANDLE(h);
+    if (!dst) return fail(HEXVEC_E_ARG, "%s", "dst is NULL");
+    HV_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->fast_mode) {
+        HV_HIP(hipMemcpyAsync(dst, h->fast, h->fast_bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        const size_t E = (size_t)h->E;
+        char *d = (char *)dst;
+        HV_HIP(hipMemcpyAsync(d, h->planes, E * hv::PLANE_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        d += E * hv::PLANE_WORDS * 4;
+        HV_HIP(hipMemcpyAsync(d, h->hot, E * hv::HOT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        d += E * hv::HOT_WORDS * 4;
+        HV_HIP(hipMemcpyAsync(d, h->stats, E * hv::STAT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return HEXVEC_OK;
+}
+
+extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
+{
+    HV_HANDLE(h);
+    if (!src) return fail(HEXVEC_E_ARG, "%s", "src is NULL");
+    HV_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (h->fast_mode) {
+        HV_HIP(hipMemcpyAsync(h->fast, src, h->fast_bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        const size_t E = (size_t)h->E;
+        const char *d = (const char *)src;
+        HV_HIP(hipMemcpyAsync(h->planes, d, E * hv::PLANE_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        d += E * hv::PLANE_WORDS * 4;
+        HV_HIP(hipMemcpyAsync(h->hot, d, E * hv::HOT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        d += E * hv::HOT_WORDS * 4;
+        HV_HIP(hipMemcpyAsync(h->stats, d, E * hv::STAT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    }
     return HEXVEC_OK;
 }
 

@@ -218,6 +218,29 @@ class HexVecEnv:
                 raise ValueError("labels must have E*2*(N+2)^2 elements")
         _lib.check(self._L.hexvec_set_state(self._h, _p(b), _p(l), int(cur_player), self._stream()))
 
+    def state_dict(self):
+        """checkpoint of the env state (boards, connectivity, players, RNG counters, episode
+        accumulators) as one opaque uint8 tensor plus the arguments it is valid for"""
+        blob = torch.empty(int(self._L.hexvec_state_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.hexvec_export_state(self._h, _p(blob), self._stream()))
+        return {"blob": blob, "board_size": self.board_size, "num_envs": self.num_envs,
+                "flags": self.flags}
+
+    def load_state_dict(self, sd):
+        if (sd["board_size"], sd["num_envs"], sd["flags"]) != (self.board_size, self.num_envs, self.flags):
+            raise ValueError("state_dict was taken from an env with different board_size/num_envs/flags")
+        blob = sd["blob"].to(self.device).contiguous()
+        if blob.numel() != int(self._L.hexvec_state_bytes(self._h)):
+            raise ValueError("state blob has the wrong size")
+        _lib.check(self._L.hexvec_import_state(self._h, _p(blob), self._stream()))
+
+    def render(self, indices=(0,)):
+        """ASCII boards of the selected envs in the reference's render() layout (HexGame.py:305-330)"""
+        from .render import board_to_text
+        board = self.get_state()[0].cpu().numpy().reshape(self.num_envs, self.board_size, self.board_size)
+        empty, black = (2, 0) if self.encoding == "A" else (0, -1)
+        return "\n".join(board_to_text(board[i], empty, black) for i in indices)
+
     def episode_stats(self):
         """float64 [4] on the device: sum_return, sum_len, n_episodes, n_agent_wins."""
         out = torch.empty(4, dtype=torch.float64, device=self.device)

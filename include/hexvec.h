@@ -167,6 +167,14 @@ int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream);
 /* agent colour per env, uint8 [E] (device) */
 int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream);
 
+/* Checkpoint / resume of the env state (the reference never saves env state; its
+ * scripts checkpoint only the SB3 model).  The blob is opaque: boards, connectivity, players,
+ * RNG counters, episode accumulators.  It restores into a handle created with the same
+ * board_size / num_envs / flags.  dst / src are device buffers of hexvec_state_bytes(). */
+size_t hexvec_state_bytes(const hexvec_t *h);
+int hexvec_export_state(hexvec_t *h, void *dst, void *stream);
+int hexvec_import_state(hexvec_t *h, const void *src, void *stream);
+
 int hexvec_board_size(const hexvec_t *h);
 int hexvec_num_envs(const hexvec_t *h);
 uint32_t hexvec_flags(const hexvec_t *h);

@@ -153,3 +153,24 @@ def test_reference_trained_actor_beats_random_play(hx):
     assert st[2] > 5 * E and st2[2] > 5 * E
     assert random_agent_winrate < 0.25, random_agent_winrate
     assert trained_agent_winrate > 0.75, trained_agent_winrate
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_state_dict_roundtrip_and_render(hx, exact):
+    n, E = 7, 200
+    a = hx.HexVecEnv(n, E, encoding="B", seed=2, exact_labels=exact)
+    for _ in range(9):
+        a.step()
+    sd = a.state_dict()
+    ref = [tuple(_np(x).copy() for x in a.step()) for _ in range(15)]
+    b = hx.HexVecEnv(n, E, encoding="B", seed=2, exact_labels=exact)
+    b.load_state_dict(sd)
+    for r in ref:
+        out = b.step()
+        for x, y in zip(out, r):
+            assert np.array_equal(_np(x), y)
+    assert np.array_equal(_np(a.episode_stats()), _np(b.episode_stats()))
+    with pytest.raises(ValueError):
+        hx.HexVecEnv(n, E + 1, encoding="B").load_state_dict(sd)
+    txt = b.render([0, 3])
+    assert txt.count("\n") == 2 * (2 + 2 * n) + 1 and "O" in txt
