@@ -26,7 +26,7 @@ MIN_BOARD, MAX_BOARD = 2, 14
 SYMBOLS = [
     "hexvec_create", "hexvec_destroy", "hexvec_reset", "hexvec_step", "hexvec_step_agent",
     "hexvec_step_opponent", "hexvec_apply_moves",
-    "hexvec_rollout_random", "hexvec_rollout_selfplay", "hexvec_get_state", "hexvec_set_state",
+    "hexvec_rollout_random", "hexvec_rollout_selfplay", "hexvec_get_state", "hexvec_set_state", "hexvec_set_boards",
     "hexvec_episode_stats", "hexvec_agent_colours", "hexvec_state_bytes", "hexvec_export_state",
     "hexvec_import_state", "hexvec_board_size", "hexvec_num_envs",
     "hexvec_flags", "hexvec_last_kernel", "hexvec_last_error",
@@ -72,6 +72,7 @@ def lib():
     L.hexvec_rollout_selfplay.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.hexvec_get_state.argtypes = [vp, vp, vp, vp, vp]
     L.hexvec_set_state.argtypes = [vp, vp, vp, i32, vp]
+    L.hexvec_set_boards.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.hexvec_episode_stats.argtypes = [vp, vp, vp]
     L.hexvec_agent_colours.argtypes = [vp, vp, vp]
     L.hexvec_state_bytes.argtypes = [vp]

@@ -75,6 +75,7 @@ static const char *lpb_kname(int mode)
     case M_ROLLOUT2: return "k_lpb<rollout2>";
     case M_STEP: return "k_lpb<step>";
     case M_ROLLOUT1: return "k_lpb<rollout1>";
+    case M_SETBOARD: return "k_lpb<set_boards>";
     default: return "k_lpb<reset>";
     }
 }
@@ -344,6 +345,22 @@ extern "C" int hexvec_set_state(hexvec_t *h, const int8_t *board, const uint8_t 
     a.labels_in = labels;
     a.cur_in = cur_player;
     return hv::run(h, hv::M_SETSTATE, a, stream);
+}
+
+extern "C" int hexvec_set_boards(hexvec_t *h, const uint8_t *env_mask, const int8_t *boards, int8_t *obs,
+                                 uint8_t *legal, uint8_t *pending, void *stream)
+{
+    HV_HANDLE(h);
+    if (!h->fast_mode)
+        return fail(HEXVEC_E_MODE, "%s", "hexvec_set_boards needs an auto-reset handle (use hexvec_set_state)");
+    if (!boards) return fail(HEXVEC_E_ARG, "%s", "boards is NULL");
+    hv::KArgs a = hv::base_args(h);
+    a.env_mask = env_mask;
+    a.board_in = (const signed char *)boards;
+    a.obs = (signed char *)obs;
+    a.legal = legal;
+    a.pending = pending;
+    return hv::run(h, hv::M_SETBOARD, a, stream);
 }
 
 extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)

@@ -17,7 +17,7 @@ constexpr int PLANE_WORDS = 3 * 64; // per env: L0, L1, F|FT<<4   (768 B)
 constexpr int HOT_WORDS = 8;  // per env: counters touched every step (32 B)
 constexpr int STAT_WORDS = 4; // per env: episode sums, touched at episode end
 
-enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5 };
+enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6 };
 
 struct KArgs {
     unsigned char *fast; // lane-per-board state (fast handles)

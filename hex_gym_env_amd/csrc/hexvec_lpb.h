@@ -505,7 +505,32 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
 
     const size_t E = (size_t)a.E;
 
-    if (MODE == M_RESET) {
+    if (MODE == M_SETBOARD) {
+        // HexEnv.reset with a given start position (sample_board, HexSingleGame.py:217-222): the
+        // stones are replayed row-major like the constructor does (:57-65); nobody has moved yet.
+        const bool sel = live && (!a.env_mask || a.env_mask[env] != 0);
+        const u64 smask = __ballot(sel);
+        if (smask) {
+            L::clear_boards(lds, smask, lane);
+            if (sel) {
+                s.pend = 0;
+                L::fresh_regs(s, first);
+                const signed char *bd = a.board_in + (size_t)env * C;
+                for (int c = 0; c < C; ++c) {
+                    const int v = bd[c];
+                    const int p = B ? (v == -1 ? 0 : (v == 1 ? 1 : -1)) : (v == 0 ? 0 : (v == 1 ? 1 : -1));
+                    if (p >= 0) {
+                        const int y = c / N, x = c - y * N;
+                        L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane);
+                    }
+                }
+                if (opens) s.pend = 2; // the opponent still owes its opening (split step)
+            }
+        }
+        if (live && a.pending) a.pending[env] = (unsigned char)s.pend;
+        L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+    } else if (MODE == M_RESET) {
         const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
         if (!a.init) L::clear_boards(lds, __ballot(sel), lane);
         if (sel) {
@@ -733,6 +758,7 @@ template <int N, int ENC> static hipError_t lpb_launch_mode(int mode, const KArg
     case M_STEP: return lpb_launch1<N, ENC, M_STEP>(a, st);
     case M_ROLLOUT1: return lpb_launch1<N, ENC, M_ROLLOUT1>(a, st);
     case M_RESET: return lpb_launch1<N, ENC, M_RESET>(a, st);
+    case M_SETBOARD: return lpb_launch1<N, ENC, M_SETBOARD>(a, st);
     default: return hipErrorInvalidValue;
     }
 }

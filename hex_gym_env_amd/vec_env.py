@@ -218,6 +218,21 @@ class HexVecEnv:
                 raise ValueError("labels must have E*2*(N+2)^2 elements")
         _lib.check(self._L.hexvec_set_state(self._h, _p(b), _p(l), int(cur_player), self._stream()))
 
+    def set_boards(self, boards, env_mask=None):
+        """start positions for the masked boards (auto-reset handles): boards int8 [E,N,N] in the
+        frame of BLACK to move -> (obs, legal, pending)"""
+        b = torch.as_tensor(boards, device=self.device).to(torch.int8).contiguous()
+        if b.numel() != self.num_envs * self.cells:
+            raise ValueError("boards must have E*N*N elements")
+        m = None
+        if env_mask is not None:
+            m = torch.as_tensor(env_mask, device=self.device).to(torch.uint8).contiguous()
+            if m.shape != (self.num_envs,):
+                raise ValueError("env_mask must have shape [num_envs]")
+        _lib.check(self._L.hexvec_set_boards(self._h, _p(m), _p(b), _p(self.obs), _p(self.legal),
+                                             _p(self.pending), self._stream()))
+        return self.obs, self.legal, self.pending
+
     def state_dict(self):
         """checkpoint of the env state (boards, connectivity, players, RNG counters, episode
         accumulators) as one opaque uint8 tensor plus the arguments it is valid for"""

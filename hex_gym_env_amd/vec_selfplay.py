@@ -23,7 +23,37 @@ import torch
 
 from .vec_env import HexVecEnv
 
-__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "VecSelfPlayEnv"]
+__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "VecSelfPlayEnv", "sample_boards"]
+
+
+def sample_boards(board_size, count, generator, device):
+    """`count` random start positions with the distribution of HexEnv.random_board
+    (HexSingleGame.py:300-331), drawn on the device: an m x l sub-rectangle (m, l uniform in
+    [N//4, N-2]) at a uniform position, holding 2*floor(m*l*(0.5+0.5u)/2) stones, half -1 (BLACK)
+    and half +1 (WHITE), uniformly arranged.  Returns int8 [count, N, N]."""
+    n = board_size
+    lo, hi = n // 4, n - 1                      # np.random.randint(n//4, n-1): [lo, hi)
+
+    def randint(a, b):                          # uniform integers in [a, b), b may be a tensor
+        u = torch.rand(count, generator=generator, device=device, dtype=torch.float64)
+        return torch.minimum((u * (b - a)).long(), torch.as_tensor(b - a - 1, device=device)) + a
+
+    m, l = randint(lo, hi), randint(lo, hi)
+    r0, c0 = randint(0, n - m + 1), randint(0, n - l + 1)
+    u = torch.rand(count, generator=generator, device=device, dtype=torch.float64)
+    stones = ((m * l).double() * (0.5 + 0.5 * u)).floor().long() // 2 * 2
+    yy = torch.arange(n, device=device).view(1, n, 1)
+    xx = torch.arange(n, device=device).view(1, 1, n)
+    inside = ((yy >= r0.view(-1, 1, 1)) & (yy < (r0 + m).view(-1, 1, 1))
+              & (xx >= c0.view(-1, 1, 1)) & (xx < (c0 + l).view(-1, 1, 1))).reshape(count, n * n)
+    keys = torch.rand((count, n * n), generator=generator, device=device)
+    keys = torch.where(inside, keys, torch.full_like(keys, 2.0))      # cells outside sort last
+    rank = keys.argsort(1).argsort(1)                                  # rank of every cell
+    half = (stones // 2).view(-1, 1)
+    board = torch.zeros((count, n * n), dtype=torch.int8, device=device)
+    board[rank < half] = -1
+    board[(rank >= half) & (rank < 2 * half)] = 1
+    return board.view(count, n, n)
 
 
 class RandomLegalPolicy:
@@ -102,7 +132,7 @@ class VecSelfPlayEnv:
     """selfplay_wrapper(HexEnv)(board_size, buffer_size, scores, ...) for num_envs boards."""
 
     def __init__(self, board_size=5, num_envs=1024, buffer_size=20, scores=None, base_model=None,
-                 agent_player_num=None, seed=0, device=None, prob_best=0.8):
+                 agent_player_num=None, seed=0, device=None, prob_best=0.8, sample_board=False):
         self.vec = HexVecEnv(board_size, num_envs, device=device, seed=seed, encoding="B",
                              agent_player_num=agent_player_num)
         self.device, self.num_envs, self.board_size = self.vec.device, num_envs, board_size
@@ -119,6 +149,7 @@ class VecSelfPlayEnv:
         self.best_score = float(np.max(self.opponent_scores))
         self.best_mean_reward = -np.inf
         self.prob_best = prob_best
+        self.sample_board = bool(sample_board)
         self.eval_state = False
         self.eval_episode = 0
         # opponent slot per board: -1 = best_model, k >= 0 = buffer slot k
@@ -152,8 +183,16 @@ class VecSelfPlayEnv:
             a = pol.choose_actions(obs[idx], legal[idx])
             self._opp[idx] = a.to(torch.int32)
 
-    def _play_opponents(self, obs, legal, pending):
-        out = None
+    def _new_positions(self, mask):
+        """sample_board: the boards in `mask` were just reset and get a random start position"""
+        if not self.sample_board or not bool(mask.any()):
+            return None
+        boards = sample_boards(self.board_size, self.num_envs, self._gen, self.device)
+        return self.vec.set_boards(boards, mask)
+
+    def _play_opponents(self, obs, legal, pending, handled):
+        """replies and openings until no board is pending; `handled` marks the boards whose end of
+        episode (new position, new opponent) has been dealt with already"""
         while bool(pending.any()):
             opening = pending == 2       # fresh boards: pick their opponent first (:75 before :79-80)
             if bool(opening.any()):
@@ -161,16 +200,30 @@ class VecSelfPlayEnv:
             self._opponent_actions(obs, legal, pending)
             out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
             obs, legal, pending = out[0], out[3], out[5]
-        return out
+            fresh = (self.vec.done != 0) & ~handled
+            handled |= fresh
+            new = self._new_positions(fresh)
+            if new is not None:
+                obs, legal, pending = new
+        return handled
 
     # -- gym-like API ----------------------------------------------------------
     def reset(self):
         """SelfPlayEnv.reset for every board (:69-89): new opponent, then it opens where the agent
-        is WHITE.  The opponent's view of the empty board is all zeros, so its opening is computed
-        up front and handed to hexvec_reset."""
+        is WHITE."""
         every = torch.arange(self.num_envs, device=self.device)
         self._setup_opponents(every)
         n = self.board_size
+        if self.sample_board:            # positions first, then the openings through the split step
+            obs, legal, pending = self._new_positions(torch.ones(self.num_envs, dtype=torch.bool,
+                                                                 device=self.device))
+            self.vec.done.zero_()
+            handled = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+            slots = self.slot.clone()
+            self._play_opponents(obs, legal, pending, handled)
+            self.slot.copy_(slots)       # the opening was played by the opponent chosen above
+            return self.vec.obs, self.vec.legal
+        # the opponent's view of the empty board is all zeros: its opening is computed up front
         empty = torch.zeros((self.num_envs, n, n), dtype=torch.int8, device=self.device)
         full = torch.ones((self.num_envs, n * n), dtype=torch.uint8, device=self.device)
         self._opponent_actions(empty, full, self.vec.agent_colours() != 0)
@@ -179,14 +232,19 @@ class VecSelfPlayEnv:
     def step(self, actions):
         """actions int [E] (agent's view) -> obs, reward, done, legal, winner.
 
-        Finished boards are reset; their opponent is re-drawn before it opens (if it opens)."""
+        Finished boards are reset (with a fresh random position if sample_board); their opponent is
+        re-drawn before it opens (if it opens)."""
         self.vec.done.zero_()        # the split calls write only the boards whose step completes
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
-        ended1 = self.vec.done != 0
-        no_opening = ended1 & (pending == 0)         # BLACK agents: a new episode, a new opponent
+        handled = self.vec.done != 0                   # ended on the agent's ply
+        ended1 = handled.clone()
+        new = self._new_positions(ended1)
+        if new is not None:
+            obs, legal, pending = new
+        no_opening = ended1 & (pending == 0)           # BLACK agents: a new episode, a new opponent
         if bool(no_opening.any()):
             self._setup_opponents(torch.nonzero(no_opening, as_tuple=False).squeeze(1))
-        self._play_opponents(obs, legal, pending)     # replies; re-draw + openings inside
+        self._play_opponents(obs, legal, pending, handled)   # replies; re-draw + openings inside
         ended2 = (self.vec.done != 0) & ~ended1 & (self.vec.agent_colours() == 0)
         if bool(ended2.any()):
             self._setup_opponents(torch.nonzero(ended2, as_tuple=False).squeeze(1))

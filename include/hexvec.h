@@ -160,6 +160,15 @@ int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uint8_t *cur_p
 int hexvec_set_state(hexvec_t *h, const int8_t *board, const uint8_t *labels, int cur_player,
                      void *stream);
 
+/* Auto-reset handles: give the boards whose env_mask byte is non-zero (NULL = all) the start
+ * position boards[e] (int8 [E,N*N], frame of BLACK to move, the handle's encoding): the reset
+ * with `sample_board` of HexSingleGame.py:217-222, the stones replayed row-major as the
+ * constructor does (:57-65).  Nobody has moved on them yet: on self-play handles where the
+ * opponent moves first they get pending = 2 (see hexvec_step_opponent).  obs / legal / pending
+ * are written for all boards. */
+int hexvec_set_boards(hexvec_t *h, const uint8_t *env_mask, const int8_t *boards, int8_t *obs,
+                      uint8_t *legal, uint8_t *pending, void *stream);
+
 /* out4 (device, double[4]) = sum of episode returns, sum of episode lengths,
  * episodes finished, episodes the agent (TWO_SIDED: BLACK) won -- since create. */
 int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream);

@@ -332,6 +332,20 @@ def gen_sample_board(HexEnvB, sizes):
             out[f"N{n}_s{k}_regions"] = env.simulator.regions.astype(np.uint8)
             b2 = env.reset()
             out[f"N{n}_s{k}_reset2_board"] = b2.astype(np.int8).copy()
+    # distribution of random_board over many draws (for the device-side sampler)
+    for n in sizes:
+        np.random.seed(9000 + n)
+        env = HexEnvB(board_size=n)
+        cnt, rows, cols = [], [], []
+        for _ in range(4000):
+            b = env.random_board(np.zeros((n, n)))
+            assert (b == -1).sum() == (b == 1).sum()
+            cnt.append(int((b != 0).sum()))
+            rows.append(int((b != 0).any(1).sum()))
+            cols.append(int((b != 0).any(0).sum()))
+        out[f"N{n}_stats_stones_hist"] = np.bincount(cnt, minlength=n * n + 1).astype(np.int32)
+        out[f"N{n}_stats_rows_hist"] = np.bincount(rows, minlength=n + 1).astype(np.int32)
+        out[f"N{n}_stats_cols_hist"] = np.bincount(cols, minlength=n + 1).astype(np.int32)
     out["sizes"] = np.array(sizes, dtype=np.int32)
     return out
 
