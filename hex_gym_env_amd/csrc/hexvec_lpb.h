@@ -221,30 +221,29 @@ template <int N, int ENC, int BPW> struct Lpb {
                 e[i] = uf[ix[i]];
             }
         }
-        // union by rank: everything hangs under the highest-rank root
+        // union by rank: everything hangs under the highest-rank root.  After the chase every e[i]
+        // is 0 (no stone) or a root byte 0xE0|rank<<2|flags; key = (rank+1)<<8 | root index.
         u32 fl = (y == 0 ? 1u : 0u) | (y == N - 1 ? 2u : 0u);
-        int best_rank = -1, best_ix = G::TRASH;
-        int rk[6];
+        u32 key[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const bool st = e[i] != 0u; // a root of colour p
-            rk[i] = st ? (int)((e[i] >> 2) & 7u) : -1;
-            fl |= st ? (e[i] & 3u) : 0u;
-            const bool better = rk[i] > best_rank;
-            best_ix = better ? ix[i] : best_ix;
-            best_rank = better ? rk[i] : best_rank;
+            fl |= e[i] & 3u;
+            key[i] = e[i] != 0u ? ((((e[i] >> 2) & 7u) + 1u) << 8) | (u32)ix[i] : 0u;
         }
-        bool tie = false;
+        const u32 best = max(max(max(key[0], key[1]), max(key[2], key[3])), max(key[4], key[5]));
+        const bool has = best != 0u;
+        const int best_ix = has ? (int)(best & 0xffu) : G::TRASH;
+        u32 second = 0u; // highest key among the OTHER roots
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const bool other = rk[i] >= 0 && ix[i] != best_ix;
-            tie = tie || (other && rk[i] == best_rank);
+            const bool other = key[i] != 0u && (key[i] & 0xffu) != (best & 0xffu);
+            second = max(second, other ? key[i] : 0u);
             uf[other ? ix[i] : G::TRASH] = (unsigned char)(best_ix + 1);
         }
-        const bool has = best_rank >= 0;
-        const u32 root_byte = 0xE0u | ((u32)(has ? best_rank + (tie ? 1 : 0) : 0) << 2) | fl;
+        const u32 rank = has ? (best >> 8) - 1u + ((second >> 8) == (best >> 8) ? 1u : 0u) : 0u;
+        const u32 root_byte = 0xE0u | (rank << 2) | fl;
         uf[a] = has ? (unsigned char)(best_ix + 1) : (unsigned char)root_byte;
-        uf[has ? best_ix : G::TRASH] = (unsigned char)root_byte;
+        uf[best_ix] = (unsigned char)root_byte; // TRASH when the stone has no neighbour of its colour
         return fl == 3u;
     }
 
