@@ -400,3 +400,50 @@ def test_lane_per_board_odd_env_counts(hx, n, E, enc):
         assert np.array_equal(_np(rew), orw), k
         assert np.array_equal(_np(done), od), k
     _same_state(g2, o2)
+
+
+@pytest.mark.parametrize("n", list(range(4, 15)))
+def test_soak_all_sizes_lane_per_board_vs_oracle(hx, n):
+    """long differential run per board size: hundreds of episodes per env, both encodings, RNG and
+    external (partly illegal) actions mixed, masked resets in between"""
+    E, K = 256, 300
+    rng = np.random.default_rng(1000 + n)
+    for enc, agent, first in (("B", None, 0), ("A", None, n % 2)):
+        g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=4242 + n)
+        for k in range(K):
+            if k % 5 == 4:
+                a = rng.integers(0, n * n, size=E).astype(np.int32)
+            else:
+                a = None
+            obs, rew, done, legal, win = g.step(a)
+            oo, ol, orw, od, ow = o.step(a)
+            assert np.array_equal(_np(rew), orw) and np.array_equal(_np(done), od), (enc, k)
+            assert np.array_equal(_np(win), ow), (enc, k)
+            if k % 7 == 0 or k == K - 1:
+                assert np.array_equal(_np(obs).reshape(E, -1), oo), (enc, k)
+                assert np.array_equal(_np(legal), ol), (enc, k)
+            if k % 97 == 50:
+                m = (rng.random(E) < 0.2).astype(np.uint8)
+                gobs, glegal = g.reset(env_mask=m)
+                oobs, olegal = o.reset(env_mask=m)
+                assert np.array_equal(_np(gobs).reshape(E, -1), oobs), (enc, k)
+                assert np.array_equal(_np(glegal), olegal), (enc, k)
+        assert o.episode_stats()[2] > 3 * E
+        _same_state(g, o)
+
+
+def test_soak_two_sided_rollout_long(hx):
+    """W2 over many launches: state carried across launches, ~10^2 episodes per env"""
+    n, E = 9, 512
+    g, o = _pair(hx, n, E, "B", two_sided=True, seed=606)
+    for launch in range(12):
+        T = 37 + launch
+        out = g.rollout_random(T, out={k: torch.empty((T, E) + ((n * n,) if k in ("obs", "legal") else ()),
+                                                      dtype=dt, device="cuda")
+                                       for k, dt in (("obs", torch.int8), ("actions", torch.int32),
+                                                     ("done", torch.uint8))})
+        oobs, olegal, oact, orew, odone = o.rollout(T)
+        assert np.array_equal(_np(out["actions"]), oact), launch
+        assert np.array_equal(_np(out["done"]), odone), launch
+        assert np.array_equal(_np(out["obs"][-1]), oobs[-1]), launch
+    _same_state(g, o)

@@ -256,3 +256,31 @@ def test_vec_selfplay_with_sampled_start_positions(hx):
         assert (own[col == 0] == opp[col == 0]).all() and (opp[col == 1] == own[col == 1] + 1).all()
         assert not bool(env.vec.pending.any())
     assert tot > E // 2 and _np(env.episode_stats())[2] == tot
+
+
+@pytest.mark.parametrize("n,E", [(7, 32768), (13, 16384)])
+def test_baseline_config_sizes_selfplay_with_mlp_policy(hx, n, E):
+    """BASELINE.json configs[2] (7x7, 32 768 envs) and configs[4] (13x13, 131 072 / 8 GPUs):
+    SelfplayWrapper semantics with an MLP policy as the agent (SB3 default 64-64 tanh net, random
+    init) and a buffer of MLP opponents; size-independent properties + the stats checksum"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    torch.manual_seed(0)
+    agent = MlpActorPolicy(n * n).to("cuda")
+    opp = MlpActorPolicy(n * n).to("cuda")
+    env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=4, base_model=opp, seed=12)
+    obs, legal = env.reset()
+    col = env.vec.agent_colours()
+    tot = 0
+    for k in range(25):
+        a = agent.choose_actions(obs, legal)
+        assert bool(torch.gather(legal, 1, a.view(-1, 1)).all())          # the mask keeps it legal
+        obs, rew, done, legal, win = env.step(a)
+        o = obs.reshape(E, -1)
+        assert torch.equal(legal, (o == 0).to(torch.uint8))
+        own, other = (o == -1).sum(1), (o == 1).sum(1)
+        assert torch.equal(own, torch.where(col == 0, other, other - 1))  # it is always the agent's turn
+        assert bool(((rew != 0) <= done.bool()).all())
+        assert bool(((win == col.to(torch.int8)) == (rew > 0))[done.bool()].all())
+        tot += int(done.sum())
+    st = _np(env.episode_stats())
+    assert st[2] == tot and st[3] == (st[0] + st[2]) / 2                  # wins - losses == sum of returns
