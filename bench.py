@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--board", type=int, default=11)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
-    ap.add_argument("--chunk", type=int, default=50, help="env steps per rollout launch")
+    ap.add_argument("--chunk", type=int, default=200, help="env steps per rollout launch")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-stepped", action="store_true")
     args = ap.parse_args()

@@ -178,16 +178,8 @@ template <int N, int ENC, int BPW> struct Lpb {
     static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int y, int x,
                                                  int lane)
     { // (y, x): coordinates of the stone in p's own frame
-        clear_bit(s.E0, idx0);
-        clear_bit(s.E1, idx1);
-        s.n_empty -= 1;
-        if (B) {
-            lds[IMG + lane * C + idx0] = p ? 1 : 0xFF;                 // view 0:  F, BLACK -1 / WHITE +1
-            lds[IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;  // view 1: -F^T
-        } else {
-            lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
-        }
-        // union-find in p's own frame
+        // union-find in p's own frame: issue the six neighbour reads first, their LDS latency is
+        // covered by the bitboard / image updates below
         unsigned char *uf = lds + (p * BPW + lane) * PS;
         const int a = p ? idx1 : idx0;
         const bool up = y > 0, dn = y < N - 1, lf = x > 0, rt = x < N - 1;
@@ -204,6 +196,15 @@ template <int N, int ENC, int BPW> struct Lpb {
         for (int i = 0; i < 6; ++i) {
             ix[i] = nb[i];
             e[i] = uf[ix[i]];
+        }
+        clear_bit(s.E0, idx0);
+        clear_bit(s.E1, idx1);
+        s.n_empty -= 1;
+        if (B) {
+            lds[IMG + lane * C + idx0] = p ? 1 : 0xFF;                 // view 0:  F, BLACK -1 / WHITE +1
+            lds[IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;  // view 1: -F^T
+        } else {
+            lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
         }
         // follow child pointers to the roots (all six chains of all lanes together)
         for (;;) {
@@ -334,40 +335,53 @@ template <int N, int ENC, int BPW> struct Lpb {
     // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`.
     // All LDS reads of the span are issued first, then merged and stored as whole 1 KiB pieces;
     // only the last piece is partial (lanes past the span re-read the last vector and skip the store).
-    template <bool OBS, bool LEGAL>
-    static __device__ __forceinline__ void emit_fast(const unsigned char *lds, u64 view1, signed char *obs,
-                                                     unsigned char *legal, int lane)
-    {
+    struct Snap {
         uint4 r0[G::NIT], r1[G::NIT];
+    };
+    static __device__ __forceinline__ void snapshot(const unsigned char *lds, Snap &sn, int lane)
+    {
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
             const int byte0 = min((it * 64 + lane) * 16, G::IMG_BYTES - 16);
-            r0[it] = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
-            if (B) r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+            sn.r0[it] = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
+            if (B) sn.r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
         }
+    }
+    template <bool OBS, bool LEGAL>
+    static __device__ __forceinline__ void finish(const Snap &sn, u64 view1, signed char *obs, unsigned char *legal,
+                                                  int lane)
+    {
 #pragma unroll
         for (int it = 0; it < G::NIT; ++it) {
             const int byte0 = (it * 64 + lane) * 16;
             uint4 o, l;
-            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), r0[it], B ? r1[it] : r0[it], o, l);
+            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], B ? sn.r1[it] : sn.r0[it], o, l);
             if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
                 if (OBS) *reinterpret_cast<uint4 *>(obs + byte0) = o;
                 if (LEGAL) *reinterpret_cast<uint4 *>(legal + byte0) = l;
             }
         }
     }
+    static __device__ __forceinline__ void finish_any(const Snap &sn, u64 view1, signed char *obs,
+                                                      unsigned char *legal, int lane)
+    {
+        if (obs && legal) finish<true, true>(sn, view1, obs, legal, lane);
+        else if (obs) finish<true, false>(sn, view1, obs, legal, lane);
+        else finish<false, true>(sn, view1, obs, legal, lane);
+    }
+    // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`.
+    // All LDS reads of the span are issued first, then merged and stored as whole 1 KiB pieces;
+    // only the last piece is partial (lanes past the span re-read the last vector and skip the store).
     static __device__ __forceinline__ void emit(const unsigned char *lds, u64 view1, signed char *obs,
                                                 unsigned char *legal, int nlive, bool vec_ok, int lane)
     {
         if (!obs && !legal) return;
         if (!(vec_ok && nlive == BPW)) {
             emit_slow(lds, view1, obs, legal, nlive * C, lane);
-        } else if (obs && legal) {
-            emit_fast<true, true>(lds, view1, obs, legal, lane);
-        } else if (obs) {
-            emit_fast<true, false>(lds, view1, obs, legal, lane);
         } else {
-            emit_fast<false, true>(lds, view1, obs, legal, lane);
+            Snap sn;
+            snapshot(lds, sn, lane);
+            finish_any(sn, view1, obs, legal, lane);
         }
     }
 };
@@ -379,17 +393,22 @@ template <int N, int ENC, int BPW> struct FastState {
     static constexpr size_t BLOCK_BYTES = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
 };
 
-template <int N, int ENC, int MODE, int BPW>
-__global__ __launch_bounds__(64) void k_lpb(KArgs a)
+// HELPER = 1: 128-thread workgroups.  Wave 0 plays; wave 1 only copies observations: at every emission
+// point wave 0 publishes the view mask and meets wave 1 at a barrier, wave 1 snapshots the images into
+// registers, a second barrier releases wave 0, and wave 1 merges and stores while wave 0 computes on.
+template <int N, int ENC, int MODE, int BPW, int HELPER>
+__global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 {
     using L = Lpb<N, ENC, BPW>;
     using G = Geo<N, BPW>;
     using LS = typename L::LS;
     constexpr bool B = ENC == 1;
     constexpr int C = G::C, JW = G::JW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES + (HELPER ? 16 : 0)];
+    u64 *sh_view = reinterpret_cast<u64 *>(lds + L::LDS_BYTES);
 
-    const int lane = (int)threadIdx.x;
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = HELPER ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int nb = (int)gridDim.x, bi = (int)blockIdx.x;
     const int blk = (nb & 7) == 0 ? (bi & 7) * (nb >> 3) + (bi >> 3) : bi; // contiguous env ranges per XCD
     const int e0 = blk * BPW;
@@ -402,6 +421,31 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
     const bool vec_ok = ((size_t)a.E * C) % 16 == 0;
+    // the helper wave copies whole aligned blocks; tail blocks / unaligned rows stay on wave 0
+    const bool helper_on = HELPER && (a.obs || a.legal) && vec_ok && nlive == BPW;
+    if (HELPER && wave == 1) {
+        if (helper_on) {
+            for (int t = 0; t < a.T; ++t) { // one emission per step (a.T == 1 outside the rollouts)
+                const size_t ob = (size_t)t * (size_t)a.E + (size_t)e0;
+                __syncthreads(); // images and view mask of this emission are final
+                const u64 view = *sh_view;
+                typename L::Snap sn;
+                L::snapshot(lds, sn, lane);
+                __syncthreads(); // the snapshot is in registers: wave 0 may play on
+                L::finish_any(sn, view, a.obs ? a.obs + ob * C : nullptr, a.legal ? a.legal + ob * C : nullptr, lane);
+            }
+        }
+        return;
+    }
+    auto do_emit = [&](u64 view, signed char *o, unsigned char *l) {
+        if (helper_on) {
+            if (lane == 0) *sh_view = view;
+            __syncthreads();
+            __syncthreads();
+        } else {
+            L::emit(lds, view, o, l, nlive, vec_ok, lane);
+        }
+    };
 
     LS s;
     s.key = mix32(((u32)env + a.env_offset) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi;
@@ -527,8 +571,8 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
             }
         }
         if (live && a.pending) a.pending[env] = (unsigned char)s.pend;
-        L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
-                a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+        do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                    a.legal ? a.legal + (size_t)e0 * C : nullptr);
     } else if (MODE == M_RESET) {
         const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
         if (!a.init) L::clear_boards(lds, __ballot(sel), lane);
@@ -538,8 +582,8 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
             if (opens) opponent_ply(a.opp_actions ? a.opp_actions[env] : L::rng_action(s, B ? s.cur : 1),
                                     a.opp_actions != nullptr);
         }
-        L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
-                a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+        do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                    a.legal ? a.legal + (size_t)e0 * C : nullptr);
     } else {
         const bool ext_a = MODE == M_STEP && a.actions, ext_o = MODE == M_STEP && a.opp_actions;
         if (MODE == M_STEP && a.phase != 0) {
@@ -588,16 +632,16 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
             handle_done(dn, won, tobs_row);
             if (dn && opens) s.pend = 2; // the opponent opens on the fresh board
             if (live && a.pending) a.pending[o] = (unsigned char)s.pend;
-            L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
-                    a.legal ? a.legal + (size_t)e0 * C : nullptr, nlive, vec_ok, lane);
+            do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
+                    a.legal ? a.legal + (size_t)e0 * C : nullptr);
         } else
         for (int t = 0; t < a.T; ++t) {
             const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
             const size_t o = ob + (size_t)lane;
             signed char *tobs_row = a.tobs ? a.tobs + ob * C : nullptr;
             if (MODE == M_ROLLOUT2)
-                L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
-                        a.legal ? a.legal + ob * C : nullptr, nlive, vec_ok, lane);
+                do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
+                    a.legal ? a.legal + ob * C : nullptr);
             // ---- slot 1: the agent's ply (two-sided: the mover's)
             int act = 0, rew = 0, won = 0, f_done = 0, f_winner = -1;
             bool reply = false; // this lane still owes the opponent's reply
@@ -669,8 +713,8 @@ __global__ __launch_bounds__(64) void k_lpb(KArgs a)
                 if (a.actions_out) a.actions_out[o] = act;
             }
             if (MODE != M_ROLLOUT2)
-                L::emit(lds, B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
-                        a.legal ? a.legal + ob * C : nullptr, nlive, vec_ok, lane);
+                do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
+                    a.legal ? a.legal + ob * C : nullptr);
         }
     }
 
@@ -747,7 +791,10 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
 template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
 {
     const int blocks = (a.E + HV_BPW - 1) / HV_BPW;
-    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW>), dim3(blocks), dim3(64), 0, st, a);
+    // the helper wave pays off where compute dominates (self-play rollout: measured +10 %); the
+    // two-sided rollout is store-bound and loses 15 % to the handshake, the others do not care
+    constexpr int HELPER = (HV_HELPER && MODE == M_ROLLOUT1) ? 1 : 0;
+    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
     return hipGetLastError();
 }
 template <int N, int ENC> static hipError_t lpb_launch_mode(int mode, const KArgs &a, hipStream_t st)

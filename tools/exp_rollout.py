@@ -23,7 +23,7 @@ def timeit(fn, n=40):
 
 
 for two in (True, False):
-    T = 64 if two else 50
+    T = int(os.environ.get("T", 64 if two else 50))
     env = hx.HexVecEnv(N, E, encoding="B", two_sided=two, seed=1)
     full = dict(obs=torch.empty((T, E, C), dtype=torch.int8, device=dev),
                 legal=torch.empty((T, E, C), dtype=torch.uint8, device=dev),
