@@ -437,11 +437,23 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         }
         return;
     }
+    // With the helper wave an emission is split: do_emit() publishes the view mask and meets the
+    // helper (barrier 1); emit_release() is the second barrier ("snapshot taken") and is called as
+    // late as possible -- right before wave 0 next touches the images -- so that wave 0 draws its
+    // next action while the helper reads LDS.
+    bool release_owed = false;
+    auto emit_release = [&]() {
+        if (release_owed) {
+            __syncthreads();
+            release_owed = false;
+        }
+    };
     auto do_emit = [&](u64 view, signed char *o, unsigned char *l) {
         if (helper_on) {
+            emit_release();
             if (lane == 0) *sh_view = view;
             __syncthreads();
-            __syncthreads();
+            release_owed = true;
         } else {
             L::emit(lds, view, o, l, nlive, vec_ok, lane);
         }
@@ -643,10 +655,12 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
                     a.legal ? a.legal + ob * C : nullptr);
             // ---- slot 1: the agent's ply (two-sided: the mover's)
-            int act = 0, rew = 0, won = 0, f_done = 0, f_winner = -1;
+            int rew = 0, won = 0, f_done = 0, f_winner = -1;
             bool reply = false; // this lane still owes the opponent's reply
+            // B: the mover's frame.  Drawn before the helper's release barrier: registers only.
+            const int act = ext_a ? (live ? a.actions[o] : 0) : L::rng_action(s, B ? s.cur : 0);
+            emit_release();
             if (live) {
-                act = ext_a ? a.actions[o] : L::rng_action(s, B ? s.cur : 0); // B: the mover's frame
                 if (two) {
                     const int mover = s.cur;
                     if (B) { // HexEnv.step (HexSingleGame.py:233-263)
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         }
     }
 
+    emit_release();
     // state back to HBM
     for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
         reinterpret_cast<uint4 *>(sblk)[i] = reinterpret_cast<const uint4 *>(lds)[i];
