@@ -1,4 +1,5 @@
-// hexvec.hip -- libhexvec: vectorised Hex for MI355X (gfx950 / CDNA4).
+// hexvec_wpb.hip -- wave-per-board kernels of libhexvec: the LITERAL engine (gfx950 / CDNA4).
+// (Throughput path: hexvec_lpb.h.  Host side / C ABI: hexvec.hip.)
 //
 // One 64-lane wavefront owns one board.  Everything the reference keeps in
 // numpy arrays lives in four VGPRs of that wave, one dword per lane:

@@ -1,6 +1,7 @@
 /*
  * hexvec.h -- C ABI of libhexvec: thousands of independent Hex games stepped in
- * lockstep on one MI355X (gfx950), one wavefront per board.
+ * lockstep on one MI355X (gfx950) by hand-written HIP kernels (one lane per board
+ * on the throughput path, one wavefront per board on the literal path; see below).
  *
  * The reference (MBPrdctns/hex_gym_env) has NO native/FFI interface: its hot
  * path sits behind plain Python classes.  Each entry point below therefore
@@ -21,8 +22,8 @@
  *     encoding B: -1 / 0 / +1 in the perspective of the player to move);
  *     legal uint8 [E, N*N] (1 = empty); actions int32 [E]; reward float32 [E];
  *     done uint8 [E]; winner/ret int8 [E]: -1 None, 0 BLACK, 1 WHITE, 3 illegal.
- *   - board_size 2..14 (labels are one byte, a padded plane is one dword per
- *     lane); larger boards are rejected with HEXVEC_E_ARG.
+ *   - board_size 2..14 (connectivity entries / labels are one byte; a padded label
+ *     plane is one dword per lane); larger boards are rejected with HEXVEC_E_ARG.
  *
  * Two kernel families serve a handle, chosen at create time:
  *   - auto-reset handles (the default) run on the lane-per-board kernels: one
