@@ -29,9 +29,23 @@ except Exception:
 
 class HexSB3VecEnv(_Base):
     def __init__(self, board_size=5, num_envs=64, agent_player_num=None, seed=0, device=None,
-                 encoding="B"):
-        self.vec = HexVecEnv(board_size, num_envs, device=device, seed=seed, encoding=encoding,
-                             agent_player_num=agent_player_num)
+                 encoding="B", buffer_size=None, scores=None, base_model=None, sample_board=False):
+        """buffer_size=None: the opponent is the library's uniform-legal policy (BaseRandomPolicy).
+        buffer_size=k: the reference's opponent buffer (selfplay_wrapper kwargs buffer_size / scores /
+        base_model / sample_board), with set_eval / get_scores / set_opponent_model ... as
+        minihex/EvaluationCallback.py:21-56 calls them on `gym_env`."""
+        self.sp = None
+        if buffer_size is not None:
+            if encoding != "B":
+                raise ValueError("the opponent buffer is the SelfplayWrapper (encoding B)")
+            from .vec_selfplay import VecSelfPlayEnv
+            self.sp = VecSelfPlayEnv(board_size, num_envs, buffer_size=buffer_size, scores=scores,
+                                     base_model=base_model, agent_player_num=agent_player_num, seed=seed,
+                                     device=device, sample_board=sample_board)
+            self.vec = self.sp.vec
+        else:
+            self.vec = HexVecEnv(board_size, num_envs, device=device, seed=seed, encoding=encoding,
+                                 agent_player_num=agent_player_num)
         n = board_size
         lo, hi = (-1, 1) if encoding == "B" else (0, 2)
         obs_space = spaces.Box(low=lo, high=hi, shape=(n, n), dtype=np.int8)
@@ -51,7 +65,7 @@ class HexSB3VecEnv(_Base):
 
     # -- VecEnv API ---------------------------------------------------------
     def reset(self):
-        obs, legal = self.vec.reset()
+        obs, legal = self.sp.reset() if self.sp is not None else self.vec.reset()
         self._masks = legal.cpu().numpy().astype(bool)
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
@@ -61,7 +75,11 @@ class HexSB3VecEnv(_Base):
         self._actions = np.asarray(actions)
 
     def step_wait(self):
-        obs, rew, done, legal, _ = self.vec.step(self._actions, terminal_obs=self._tobs)
+        if self.sp is not None:
+            obs, rew, done, legal, _ = self.sp.step(self._actions)
+            self._tobs = self.sp.terminal_obs
+        else:
+            obs, rew, done, legal, _ = self.vec.step(self._actions, terminal_obs=self._tobs)
         obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
         done_h = done.cpu().numpy().astype(bool)
         self._masks = legal.cpu().numpy().astype(bool)
@@ -112,6 +130,31 @@ class HexSB3VecEnv(_Base):
 
     def env_is_wrapped(self, wrapper_class, indices=None):
         return [False for _ in self._indices(indices)]
+
+    # -- what SelfPlayCallback calls on gym_env (EvaluationCallback.py:31-54) -------------
+    def _buffer(self):
+        if self.sp is None:
+            raise AttributeError("created without buffer_size: there is no opponent buffer")
+        return self.sp
+
+    def set_eval(self, eval_state):
+        self._buffer().set_eval(eval_state)
+
+    def get_scores(self):
+        return self._buffer().get_scores()
+
+    def get_opponent_models(self):
+        return self._buffer().get_opponent_models()
+
+    def set_opponent_model(self, index, model, score):
+        self._buffer().set_opponent_model(index, model, score)
+
+    def save_best_model(self):
+        self._buffer().save_best_model()
+
+    @property
+    def best_score(self):
+        return self._buffer().best_score
 
     def seed(self, seed=None):
         return [None] * self.num_envs

@@ -23,7 +23,8 @@ import torch
 
 from .vec_env import HexVecEnv
 
-__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "VecSelfPlayEnv", "sample_boards"]
+__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "PredictAdapter", "as_policy", "VecSelfPlayEnv",
+           "sample_boards"]
 
 
 def sample_boards(board_size, count, generator, device):
@@ -128,6 +129,34 @@ class MlpActorPolicy(torch.nn.Module):
         torch.save(self.state_dict(), path)
 
 
+class PredictAdapter:
+    """Any model with the SB3 contract  predict(obs, deterministic=..., action_masks=...) -> (actions, _)
+    (what the reference's OpponentPolicy wraps, SelfplayWrapper.py:26-35), called once per group of
+    boards with batched numpy inputs.  The model object is kept by reference, like the reference does
+    (set_opponent_model stores the live model, :125-136)."""
+
+    def __init__(self, model, deterministic=False):
+        self.opponent_model = model
+        self.deterministic = deterministic
+
+    def choose_actions(self, obs, legal):
+        a, _ = self.opponent_model.predict(obs.cpu().numpy(), deterministic=self.deterministic,
+                                           action_masks=legal.cpu().numpy().astype(bool))
+        return torch.as_tensor(np.asarray(a), device=obs.device).long()
+
+    def save_model(self, path):
+        self.opponent_model.save(path)
+
+
+def as_policy(model):
+    """device policy for whatever set_opponent_model() is given"""
+    if hasattr(model, "choose_actions"):
+        return model
+    if hasattr(model, "predict"):
+        return PredictAdapter(model)
+    raise TypeError("an opponent needs choose_actions(obs, legal) or predict(obs, deterministic, action_masks)")
+
+
 class VecSelfPlayEnv:
     """selfplay_wrapper(HexEnv)(board_size, buffer_size, scores, ...) for num_envs boards."""
 
@@ -143,6 +172,7 @@ class VecSelfPlayEnv:
             self.opponent_scores = np.zeros(buffer_size)
             self.best_model = RandomLegalPolicy(self._gen)
         else:                            # :54-57
+            base_model = as_policy(base_model)
             self.opponent_models = [base_model for _ in range(buffer_size)]
             self.opponent_scores = np.zeros(buffer_size) if scores is None else np.asarray(scores, float)
             self.best_model = base_model
@@ -269,6 +299,7 @@ class VecSelfPlayEnv:
         return self.best_mean_reward
 
     def set_opponent_model(self, index, model, score):
+        model = as_policy(model)
         self.opponent_models[index] = model
         self.opponent_scores[index] = score
         if score > self.best_score:

@@ -284,3 +284,52 @@ def test_baseline_config_sizes_selfplay_with_mlp_policy(hx, n, E):
         tot += int(done.sum())
     st = _np(env.episode_stats())
     assert st[2] == tot and st[3] == (st[0] + st[2]) / 2                  # wins - losses == sum of returns
+
+
+def test_sb3_adapter_with_opponent_buffer_and_callback_surface(hx):
+    """the calls of minihex/EvaluationCallback.py:21-56 against the vectorised env, with SB3-style
+    models (predict(obs, deterministic, action_masks)) as buffer entries"""
+    from hex_gym_env_amd.sb3_adapter import HexSB3VecEnv
+
+    class FakeSB3Model:
+        n_calls = 0
+
+        def predict(self, obs, deterministic=False, action_masks=None):
+            FakeSB3Model.n_calls += 1
+            assert obs.ndim == 3 and action_masks.shape == (obs.shape[0], obs.shape[1] * obs.shape[2])
+            return np.array([np.flatnonzero(m)[-1] for m in action_masks]), None     # last legal cell
+
+        def save(self, path):
+            self.saved = path
+
+    n, E, K = 5, 128, 4
+    venv = HexSB3VecEnv(board_size=n, num_envs=E, buffer_size=K, scores=np.zeros(K), seed=1)
+    obs = venv.reset()
+    model = FakeSB3Model()
+    # --- the callback's sequence
+    venv.set_eval(True)
+    venv.reset()
+    venv.set_eval(False)
+    scores = venv.get_scores()
+    assert len(venv.get_opponent_models()) == K and scores.shape == (K,)
+    worst = np.arange(K)[scores == np.min(scores)]
+    venv.set_opponent_model(int(worst[0]), model, 0.9)
+    assert venv.best_score == 0.9 and venv.get_scores()[worst[0]] == 0.9
+    venv.save_best_model()
+    assert model.saved.startswith("models/best_model_")
+    # --- the new best model now answers ~80 % of the boards: its stones sit at the LAST cell of
+    #     the opponent's view, i.e. at cell (N-1,N-1) transposed = the agent's last cell
+    obs = venv.reset()
+    rng = np.random.default_rng(0)
+    ends = 0
+    for k in range(30):
+        masks = np.stack(venv.env_method("action_masks"))
+        acts = np.array([rng.choice(np.flatnonzero(m)) for m in masks])
+        obs, rew, done, infos = venv.step(acts)
+        ends += int(done.sum())
+        for i in np.flatnonzero(done):
+            assert "terminal_observation" in infos[i] and infos[i]["episode"]["l"] >= 1
+    assert FakeSB3Model.n_calls >= 30 and ends > 0
+    with pytest.raises(AttributeError):
+        HexSB3VecEnv(board_size=n, num_envs=8).set_eval(True)
+    venv.close()
