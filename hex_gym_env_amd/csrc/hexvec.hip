@@ -29,6 +29,25 @@ static int fail(int code, const char *fmt, const char *detail)
     snprintf(g_err, sizeof(g_err), fmt, detail);
     return code;
 }
+// The caller's current device (PyTorch tracks it through the runtime) is restored on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+#define HV_DEVICE(h)                                                        \
+    DeviceGuard dev_guard_((h)->device);                                    \
+    if (!dev_guard_.ok) return fail(HEXVEC_E_HIP, "%s", "hipSetDevice failed")
+
 #define HV_HIP(call)                                                              \
     do {                                                                          \
         hipError_t e_ = (call);                                                   \
@@ -82,7 +101,7 @@ static const char *lpb_kname(int mode)
 
 static int run(hexvec *h, int mode, const KArgs &a, void *stream)
 {
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
     if (h->fast_mode) {
         g_kernel = lpb_kname(mode);
@@ -112,7 +131,8 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(HEXVEC_E_NOGPU, "%s", "no HIP device visible: libhexvec has no CPU path");
     if (device_id < 0 || device_id >= ndev) return fail(HEXVEC_E_NOGPU, "%s", "device_id out of range");
-    HV_HIP(hipSetDevice(device_id));
+    DeviceGuard dev_guard_(device_id);
+    if (!dev_guard_.ok) return fail(HEXVEC_E_HIP, "%s", "hipSetDevice failed");
     hexvec *h = new hexvec();
     h->N = board_size;
     h->E = num_envs;
@@ -165,7 +185,7 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
 extern "C" int hexvec_destroy(hexvec_t *h)
 {
     if (!h) return HEXVEC_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard_(h->device);
     if (h->planes) (void)hipFree(h->planes);
     if (h->hot) (void)hipFree(h->hot);
     if (h->stats) (void)hipFree(h->stats);
@@ -314,7 +334,7 @@ extern "C" int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uin
                                 void *stream)
 {
     HV_HANDLE(h);
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     if (h->fast_mode) {
         if (labels)
             return fail(HEXVEC_E_MODE, "%s",
@@ -367,7 +387,7 @@ extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)
 {
     HV_HANDLE(h);
     if (!out4) return fail(HEXVEC_E_ARG, "%s", "out4 is NULL");
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
@@ -384,7 +404,7 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
 {
     HV_HANDLE(h);
     if (!out) return fail(HEXVEC_E_ARG, "%s", "out is NULL");
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
@@ -409,7 +429,7 @@ extern "C" int hexvec_export_state(hexvec_t *h, void *dst, void *stream)
 {
     HV_HANDLE(h);
     if (!dst) return fail(HEXVEC_E_ARG, "%s", "dst is NULL");
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     if (h->fast_mode) {
         HV_HIP(hipMemcpyAsync(dst, h->fast, h->fast_bytes, hipMemcpyDeviceToDevice, st));
@@ -429,7 +449,7 @@ extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
 {
     HV_HANDLE(h);
     if (!src) return fail(HEXVEC_E_ARG, "%s", "src is NULL");
-    HV_HIP(hipSetDevice(h->device));
+    HV_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     if (h->fast_mode) {
         HV_HIP(hipMemcpyAsync(h->fast, src, h->fast_bytes, hipMemcpyDeviceToDevice, st));
