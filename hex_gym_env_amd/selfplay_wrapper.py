@@ -1,40 +1,47 @@
-"""selfplay_wrapper: the reference's minihex/SelfplayWrapper.py surface (single env).
+"""selfplay_wrapper: the reference's minihex/SelfplayWrapper.py surface for ONE board.
 
-SelfPlayEnv.step = agent ply, then the opponent's ply chosen by a policy from the
-opponent buffer, agent-indexed reward (SelfplayWrapper.py:174-199).  The python
-`random` call sequence of the reference is kept (agent colour :72-73, 80/20 opponent
-choice :97-104, the unused draw in continue_game :159, BaseRandomPolicy :20), so a
-seeded run reproduces the reference's trajectory.
+SelfPlayEnv.step = the agent's ply, then the opponent's ply chosen by a policy from the
+opponent pool, agent-indexed reward (SelfplayWrapper.py:174-199).  The pool bookkeeping lives in
+OpponentBuffer (shared with the vectorised VecSelfPlayEnv); this class only sequences the two
+plies on the libhexvec-backed HexEnv and draws from python's `random` in the same order as the
+reference (agent colour :72-73, 80/20 choice :97-104, the discarded draw of continue_game :159,
+BaseRandomPolicy :20), so that a seeded run reproduces the reference's trajectory.
 """
 import random
 
 import numpy as np
 
-from .hex_single_game import player  # noqa: F401  (same dict as the reference module exports)
+from .hex_single_game import player  # noqa: F401  (re-exported like the reference module does)
+from .opponent_buffer import OpponentBuffer
 
 
 class BaseRandomPolicy(object):
+    """uniform over the empty cells of the board it is shown (python `random` stream)"""
+
     def choose_action(self, board, action_mask=None):
-        valid = np.flatnonzero(np.asarray(board).ravel() == 0)
-        return valid[int(random.random() * len(valid))]
+        empties = np.flatnonzero(np.asarray(board).ravel() == 0)
+        return empties[int(random.random() * len(empties))]
 
     def save_model(self, path):
         return None
 
 
 class OpponentPolicy(object):
+    """an SB3-style model as opponent: predict(board, deterministic=False, action_masks=mask)"""
+
     def __init__(self, model):
         self.opponent_model = model
 
     def choose_action(self, board, action_mask=None):
-        action, _ = self.opponent_model.predict(board, deterministic=False, action_masks=action_mask)
-        return action
+        return self.opponent_model.predict(board, deterministic=False, action_masks=action_mask)[0]
 
     def save_model(self, path):
         self.opponent_model.save(path)
 
 
 def selfplay_wrapper(env):
+    """class factory, as in the reference: selfplay_wrapper(HexEnv)(board_size=..., buffer_size=..., ...)"""
+
     class SelfPlayEnv(env):
         def __init__(self, base_model=BaseRandomPolicy(), scores=np.zeros(20), play_gui=False,
                      board_size=5, buffer_size=20, sample_board=False, prob_model=None,
@@ -43,20 +50,58 @@ def selfplay_wrapper(env):
                 raise NotImplementedError("the pygame GUI is out of scope of hex_gym_env_amd")
             super(SelfPlayEnv, self).__init__(board_size=board_size, sample_board=sample_board, **kwargs)
             self.agent_player_num = agent_player_num
-            self.calculate_probs = False
-            if type(base_model) != BaseRandomPolicy:
-                self.opponent_models = np.array([OpponentPolicy(base_model) for _ in range(buffer_size)])
-                self.opponent_scores = scores
-                base_model = OpponentPolicy(base_model)
-            else:
-                self.opponent_models = np.array([BaseRandomPolicy() for _ in range(buffer_size)])
-                self.opponent_scores = np.zeros(buffer_size)
-            self.best_model = base_model
-            self.best_score = np.max(self.opponent_scores)
-            self.best_mean_reward = -np.inf
-            self.eval_state = False
-            self.eval_episode = 0
             self.play_gui = False
+            self.calculate_probs = False
+            if type(base_model) is BaseRandomPolicy:      # :58-60 random pool, zero scores
+                pool = [BaseRandomPolicy() for _ in range(buffer_size)]
+                self.buffer = OpponentBuffer(pool, np.zeros(buffer_size), base_model, verbose=True)
+            else:                                         # :54-57 the given model everywhere
+                wrapped = OpponentPolicy(base_model)
+                pool = [OpponentPolicy(base_model) for _ in range(buffer_size)]
+                self.buffer = OpponentBuffer(pool, scores, wrapped, verbose=True)
+            self.opponent_model = None
+
+        # -- the reference's attribute names, backed by the buffer ---------------------------
+        opponent_models = property(lambda self: np.array(self.buffer.members, dtype=object))
+        opponent_scores = property(lambda self: self.buffer.scores)
+        best_model = property(lambda self: self.buffer.best)
+        best_score = property(lambda self: self.buffer.best_score)
+        best_mean_reward = property(lambda self: self.buffer.best_mean_reward)
+        eval_state = property(lambda self: self.buffer.evaluating)
+        eval_episode = property(lambda self: self.buffer.eval_cursor)
+
+        def set_eval(self, eval_state):
+            self.buffer.set_eval(eval_state)
+
+        def get_scores(self):
+            return self.buffer.scores
+
+        def get_opponent_models(self):
+            return self.buffer.members
+
+        def get_best_mean_reward(self):
+            return self.buffer.best_mean_reward
+
+        def set_opponent_model(self, index, model, score):
+            self.buffer.replace(index, OpponentPolicy(model), score)
+
+        def append_opponent_model(self, opponent_model, best_model=False, mean_reward=None):
+            # (the reference calls ndarray.append here, SelfplayWrapper.py:112, and raises)
+            self.buffer.append(OpponentPolicy(opponent_model), best_model, mean_reward)
+
+        def save_best_model(self):
+            self.buffer.save_best()
+
+        # -- episode flow -------------------------------------------------------------------------
+        def setup_opponents(self):
+            if self.buffer.evaluating:
+                k = self.buffer.next_eval_slot(wrap=False)
+                if k is not None:                        # exhausted walk: keep the last opponent
+                    self.opponent_model = self.buffer.policy(k)
+                return
+            u = random.uniform(0, 1)
+            slot = self.buffer.pick(u, random.random() if u >= self.buffer.prob_best else 0.0)
+            self.opponent_model = self.buffer.policy(slot)
 
         def reset(self, seed=None, options=None):
             super(SelfPlayEnv, self).reset()
@@ -64,69 +109,20 @@ def selfplay_wrapper(env):
                 self.agent_player_num = random.randint(0, 1)
             self.setup_opponents()
             if self.current_player_num != self.agent_player_num:
-                self.continue_game()
-            info = {"state": self.simulator.board, "last_move_opponent": None, "last_move_player": None}
-            return self.simulator.board, info
-
-        def setup_opponents(self):
-            if self.eval_state:
-                if self.eval_episode <= len(self.opponent_models) - 1:
-                    self.opponent_model = self.opponent_models[self.eval_episode]
-                    self.eval_episode += 1
-                return None
-            if random.uniform(0, 1) < 0.8:
-                self.opponent_model = self.best_model
-            else:
-                self.opponent_model = self.opponent_models[int(random.random() * len(self.opponent_models))]
-
-        def append_opponent_model(self, opponent_model, best_model=False, mean_reward=None):
-            new_opponent = OpponentPolicy(opponent_model)
-            if best_model:
-                self.best_model = new_opponent
-                self.best_mean_reward = mean_reward
-            # the reference calls ndarray.append here (SelfplayWrapper.py:112) and raises
-            self.opponent_models = np.append(self.opponent_models, new_opponent)
-            self.opponent_scores = np.append(self.opponent_scores, 0.0)
-
-        def get_best_mean_reward(self):
-            return self.best_mean_reward
-
-        def set_eval(self, eval_state):
-            self.eval_episode = 0
-            self.eval_state = eval_state
-            assert len(self.opponent_models) == len(self.opponent_scores)
-
-        def get_scores(self):
-            return self.opponent_scores
-
-        def set_opponent_model(self, index, model, score):
-            print("Previous model scores: ", self.opponent_scores)
-            model = OpponentPolicy(model)
-            self.opponent_models[index] = model
-            self.opponent_scores[index] = score
-            print("Replaced model from index: ", index)
-            print("Model score: ", score)
-            if score > self.best_score:
-                self.best_model = model
-                self.best_score = score
-                print("NEW BEST MODEL WITH SCORE: ", score)
-
-        def get_opponent_models(self):
-            return self.opponent_models
-
-        def save_best_model(self):
-            self.best_model.save_model("models/best_model_" + str(self.best_score))
+                self.continue_game()                     # the opponent opens
+            board = self.simulator.board
+            return board, {"state": board, "last_move_opponent": None, "last_move_player": None}
 
         def continue_game(self):
-            random.uniform(0, 1)      # SelfplayWrapper.py:159 draws and discards one number
-            action = self.opponent_model.choose_action(self.simulator.board, self.legal_actions())
-            observation, reward, done, _ = super(SelfPlayEnv, self).step(action)
-            return observation, reward, done, None
+            random.uniform(0, 1)                         # :159 draws one number and discards it
+            move = self.opponent_model.choose_action(self.simulator.board, self.legal_actions())
+            obs, reward, done, _ = super(SelfPlayEnv, self).step(move)
+            return obs, reward, done, None
 
         def step(self, action):
-            observation, reward, done, _ = super(SelfPlayEnv, self).step(action)
+            obs, reward, done, _ = super(SelfPlayEnv, self).step(action)
             if not done:
-                observation, reward, done, _ = self.continue_game()
-            return observation, reward[self.agent_player_num], done, False, {}
+                obs, reward, done, _ = self.continue_game()
+            return obs, reward[self.agent_player_num], done, False, {}
 
     return SelfPlayEnv

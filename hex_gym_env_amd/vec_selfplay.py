@@ -21,6 +21,7 @@ import zipfile
 import numpy as np
 import torch
 
+from .opponent_buffer import OpponentBuffer
 from .vec_env import HexVecEnv
 
 __all__ = ["RandomLegalPolicy", "MlpActorPolicy", "PredictAdapter", "as_policy", "VecSelfPlayEnv",
@@ -167,40 +168,42 @@ class VecSelfPlayEnv:
         self.device, self.num_envs, self.board_size = self.vec.device, num_envs, board_size
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(int(seed) + 0x5EED)
-        if base_model is None:           # SelfplayWrapper.py:58-60
-            self.opponent_models = [RandomLegalPolicy(self._gen) for _ in range(buffer_size)]
-            self.opponent_scores = np.zeros(buffer_size)
-            self.best_model = RandomLegalPolicy(self._gen)
-        else:                            # :54-57
+        if base_model is None:           # SelfplayWrapper.py:58-60: random pool, zero scores
+            pool = [RandomLegalPolicy(self._gen) for _ in range(buffer_size)]
+            self.buffer = OpponentBuffer(pool, np.zeros(buffer_size), RandomLegalPolicy(self._gen), prob_best)
+        else:                            # :54-57: the given model in every slot
             base_model = as_policy(base_model)
-            self.opponent_models = [base_model for _ in range(buffer_size)]
-            self.opponent_scores = np.zeros(buffer_size) if scores is None else np.asarray(scores, float)
-            self.best_model = base_model
-        self.best_score = float(np.max(self.opponent_scores))
-        self.best_mean_reward = -np.inf
-        self.prob_best = prob_best
+            pool = [base_model for _ in range(buffer_size)]
+            self.buffer = OpponentBuffer(pool, np.zeros(buffer_size) if scores is None else scores,
+                                         base_model, prob_best)
         self.sample_board = bool(sample_board)
-        self.eval_state = False
-        self.eval_episode = 0
         # opponent slot per board: -1 = best_model, k >= 0 = buffer slot k
         self.slot = torch.full((num_envs,), -1, dtype=torch.long, device=self.device)
         self._opp = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
         self.terminal_obs = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8,
                                         device=self.device)
 
-    # -- opponent selection (setup_opponents, :91-104) -----------------------
+    # the reference's attribute names
+    opponent_models = property(lambda self: self.buffer.members)
+    opponent_scores = property(lambda self: self.buffer.scores)
+    best_model = property(lambda self: self.buffer.best)
+    best_score = property(lambda self: self.buffer.best_score)
+    best_mean_reward = property(lambda self: self.buffer.best_mean_reward)
+    eval_state = property(lambda self: self.buffer.evaluating)
+
+    # -- opponent selection (setup_opponents, :91-104), one slot per board ------------------
     def _setup_opponents(self, idx):
         n = int(idx.numel())
         if n == 0:
             return
-        if self.eval_state:              # walk the buffer in order, one slot per episode
-            k = (torch.arange(n, device=self.device) + self.eval_episode) % len(self.opponent_models)
-            self.eval_episode += n
+        if self.buffer.evaluating:       # walk the pool in order, one member per new episode
+            k = (torch.arange(n, device=self.device) + self.buffer.eval_cursor) % len(self.buffer)
+            self.buffer.eval_cursor += n
             self.slot[idx] = k
             return
         u = torch.rand(n, generator=self._gen, device=self.device)
-        k = torch.randint(len(self.opponent_models), (n,), generator=self._gen, device=self.device)
-        self.slot[idx] = torch.where(u < self.prob_best, torch.full_like(k, -1), k)
+        k = torch.randint(len(self.buffer), (n,), generator=self._gen, device=self.device)
+        self.slot[idx] = torch.where(u < self.buffer.prob_best, torch.full_like(k, -1), k)
 
     def _opponent_actions(self, obs, legal, pending):
         idx_all = torch.nonzero(pending, as_tuple=False).squeeze(1)
@@ -209,7 +212,7 @@ class VecSelfPlayEnv:
         slots = self.slot[idx_all]
         for k in torch.unique(slots).tolist():
             idx = idx_all[slots == k]
-            pol = self.best_model if k < 0 else self.opponent_models[k]
+            pol = self.buffer.policy(k)
             a = pol.choose_actions(obs[idx], legal[idx])
             self._opp[idx] = a.to(torch.int32)
 
@@ -285,29 +288,22 @@ class VecSelfPlayEnv:
 
     # -- buffer API (SelfplayWrapper.py:106-144) -------------------------------
     def set_eval(self, eval_state):
-        self.eval_episode = 0
-        self.eval_state = bool(eval_state)
-        assert len(self.opponent_models) == len(self.opponent_scores)
+        self.buffer.set_eval(eval_state)
 
     def get_scores(self):
-        return self.opponent_scores
+        return self.buffer.scores
 
     def get_opponent_models(self):
-        return self.opponent_models
+        return self.buffer.members
 
     def get_best_mean_reward(self):
-        return self.best_mean_reward
+        return self.buffer.best_mean_reward
 
     def set_opponent_model(self, index, model, score):
-        model = as_policy(model)
-        self.opponent_models[index] = model
-        self.opponent_scores[index] = score
-        if score > self.best_score:
-            self.best_model = model
-            self.best_score = score
+        self.buffer.replace(index, as_policy(model), score)
 
     def save_best_model(self, path=None):
-        self.best_model.save_model(path or ("models/best_model_" + str(self.best_score)))
+        self.buffer.save_best(path)
 
     def episode_stats(self):
         return self.vec.episode_stats()
