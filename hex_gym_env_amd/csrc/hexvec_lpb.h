@@ -81,6 +81,8 @@ template <int N, int ENC, int BPW> struct Lpb {
         int n_empty;
         int agent;
         int pend; // split step: 0 agent to move, 1 the opponent owes its reply, 2 its opening
+        int prewon; // bit p: colour p was already connected in the start position (set_boards); the
+                    // reference notices that on p's next ply, whatever it is (HexGame.py:101-105)
         u32 ctr, key;
         int ep_ret, ep_len;
         int sr, sl, se, sw;
@@ -171,6 +173,7 @@ template <int N, int ENC, int BPW> struct Lpb {
         s.n_empty = C;
         s.ep_ret = 0;
         s.ep_len = 0;
+        s.prewon = 0;
     }
 
     // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.winner = (int)((fl >> 4) & 7) - 1;
         s.n_empty = (int)(fl >> 8) & 0xff;
         s.pend = (int)(fl >> 16) & 3;
+        s.prewon = (int)(fl >> 18) & 3;
         s.sr = (int)r[4 * 64 + lane];
         s.sl = (int)r[5 * 64 + lane];
         s.se = (int)r[6 * 64 + lane];
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         if (check && (!inb || !L::test_bit(s.E0, idx0))) return 3;
         const int p = s.cur;
         const bool same = p == fr; // the plane of colour p is indexed in p's own frame
-        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane);
+        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane) || ((s.prewon >> p) & 1);
         int ret = -1;
         if (win) {
             s.done = 1;
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                     const int p = B ? (v == -1 ? 0 : (v == 1 ? 1 : -1)) : (v == 0 ? 0 : (v == 1 ? 1 : -1));
                     if (p >= 0) {
                         const int y = c / N, x = c - y * N;
-                        L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane);
+                        if (L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane)) s.prewon |= 1 << p;
                     }
                 }
                 if (opens) s.pend = 2; // the opponent still owes its opening (split step)
@@ -746,7 +750,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     r[1 * 64 + lane] = (u32)s.ep_ret;
     r[2 * 64 + lane] = (u32)s.ep_len;
     r[3 * 64 + lane] = (u32)s.cur | ((u32)s.done << 2) | ((u32)s.agent << 3) | ((u32)(s.winner + 1) << 4) |
-                       ((u32)(s.n_empty & 0xff) << 8) | ((u32)s.pend << 16);
+                       ((u32)(s.n_empty & 0xff) << 8) | ((u32)s.pend << 16) | ((u32)s.prewon << 18);
     r[4 * 64 + lane] = (u32)s.sr;
     r[5 * 64 + lane] = (u32)s.sl;
     r[6 * 64 + lane] = (u32)s.se;

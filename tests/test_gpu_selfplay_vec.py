@@ -333,3 +333,43 @@ def test_sb3_adapter_with_opponent_buffer_and_callback_surface(hx):
     with pytest.raises(AttributeError):
         HexSB3VecEnv(board_size=n, num_envs=8).set_eval(True)
     venv.close()
+
+
+def test_prewon_start_position_is_noticed_on_the_next_ply(hx):
+    """quirk q9: a start position in which a colour is already connected ends the game on that
+    colour's next ply wherever it is played (the reference tests regions[cur][-1,-1] after every move
+    of the mover, HexGame.py:101-105) -- fast path == exact engine"""
+    n, E = 5, 64
+    b = torch.zeros((E, n, n), dtype=torch.int8, device="cuda")
+    b[:, :, 2] = -1                      # BLACK column: top-bottom connected
+    b[:, 0, 0] = 1
+    b[:, 4, 4] = 1                       # some WHITE stones, not connected
+    fast = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=1, auto_reset=True)
+    exact = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=1, exact_labels=True)
+    fast.set_boards(b)
+    exact.set_state(b.reshape(E, -1))
+    a = torch.full((E,), 1, dtype=torch.int32, device="cuda")       # BLACK plays a cell away from the column
+    fo = [x.clone() for x in fast.step(a)]
+    eo = exact.step(a)
+    for x, y in zip(fo, eo):
+        assert torch.equal(x, y)
+    assert bool(fo[2].all()) and bool((fo[1] == 1).all())          # done, reward +1 for BLACK
+
+
+def test_entry_points_reject_wrong_handle_modes(hx):
+    fast2 = hx.HexVecEnv(5, 8, encoding="B", two_sided=True)
+    fastsp = hx.HexVecEnv(5, 8, encoding="B")
+    exact = hx.HexVecEnv(5, 8, encoding="B", two_sided=True, auto_reset=False)
+    z = np.zeros((3, 8), np.int32)
+    for fn in (lambda: fast2.apply_moves(z),                       # literal plies need an exact handle
+               lambda: fastsp.rollout_random(4),                   # two-sided only
+               lambda: fast2.rollout_selfplay(4),                  # self-play only
+               lambda: exact.rollout_random(4),                    # needs auto reset
+               lambda: exact.step_agent(),                         # split step: fast self-play handles
+               lambda: fast2.step_agent(),
+               lambda: exact.set_boards(np.zeros((8, 5, 5), np.int8)),
+               lambda: fastsp.set_state(np.zeros((8, 25), np.int8))):
+        with pytest.raises(RuntimeError):
+            fn()
+    assert fastsp.get_state()[1] is None and exact.get_state()[1] is not None
+    assert fastsp.rollout_selfplay(0, out={}) == {}                # T = 0 is a no-op
