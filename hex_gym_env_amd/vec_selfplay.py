@@ -182,6 +182,9 @@ class VecSelfPlayEnv:
         self._opp = torch.zeros(num_envs, dtype=torch.int32, device=self.device)
         self.terminal_obs = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8,
                                         device=self.device)
+        self._white = self.vec.agent_colours() != 0       # fixed per board (SelfplayWrapper.py:72-73)
+        self._any_white = bool(self._white.any())          # one host read, at construction
+        self._eval_cursor = torch.zeros((), dtype=torch.long, device=self.device)
 
     # the reference's attribute names
     opponent_models = property(lambda self: self.buffer.members)
@@ -192,95 +195,104 @@ class VecSelfPlayEnv:
     eval_state = property(lambda self: self.buffer.evaluating)
 
     # -- opponent selection (setup_opponents, :91-104), one slot per board ------------------
-    def _setup_opponents(self, idx):
-        n = int(idx.numel())
-        if n == 0:
-            return
+    # Everything below is mask based and never reads a device value on the host: no
+    # synchronisation inside step().
+    def _draw_candidates(self):
+        """one candidate slot per board for this step (a board ends at most once per step)"""
+        E = self.num_envs
+        u = torch.rand(E, generator=self._gen, device=self.device)
+        k = torch.randint(len(self.buffer), (E,), generator=self._gen, device=self.device)
+        self._cand = torch.where(u < self.buffer.prob_best, torch.full_like(k, -1), k)
+
+    def _setup_opponents(self, mask):
+        """new opponent slot for the boards in `mask` (bool [E]); the others keep theirs"""
         if self.buffer.evaluating:       # walk the pool in order, one member per new episode
-            k = (torch.arange(n, device=self.device) + self.buffer.eval_cursor) % len(self.buffer)
-            self.buffer.eval_cursor += n
-            self.slot[idx] = k
-            return
-        u = torch.rand(n, generator=self._gen, device=self.device)
-        k = torch.randint(len(self.buffer), (n,), generator=self._gen, device=self.device)
-        self.slot[idx] = torch.where(u < self.buffer.prob_best, torch.full_like(k, -1), k)
+            rank = torch.cumsum(mask.to(torch.long), 0) - 1
+            new = (rank + self._eval_cursor) % len(self.buffer)
+            self._eval_cursor = self._eval_cursor + mask.sum()      # device-side cursor
+        else:
+            new = self._cand
+        self.slot = torch.where(mask, new, self.slot)
 
     def _opponent_actions(self, obs, legal, pending):
-        idx_all = torch.nonzero(pending, as_tuple=False).squeeze(1)
-        if idx_all.numel() == 0:
-            return
-        slots = self.slot[idx_all]
-        for k in torch.unique(slots).tolist():
-            idx = idx_all[slots == k]
-            pol = self.buffer.policy(k)
-            a = pol.choose_actions(obs[idx], legal[idx])
-            self._opp[idx] = a.to(torch.int32)
+        """actions of every pending board's opponent.  Boards are grouped by distinct policy OBJECT
+        (the reference's pool mostly holds the same live model); each distinct policy is evaluated
+        on the whole batch and its answers are kept where that policy is the opponent."""
+        groups = {}
+        for k in range(-1, len(self.buffer)):
+            groups.setdefault(id(self.buffer.policy(k)), (self.buffer.policy(k), []))[1].append(k)
+        safe_legal = torch.where(pending.view(-1, 1).bool(), legal, torch.ones_like(legal))
+        first = True
+        for pol, slots in groups.values():
+            a = pol.choose_actions(obs, safe_legal).to(torch.int32)
+            if first and len(groups) == 1:
+                self._opp = a
+                return
+            first = False
+            member = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+            for k in slots:
+                member |= self.slot == k
+            self._opp = torch.where(member, a, self._opp)
 
     def _new_positions(self, mask):
         """sample_board: the boards in `mask` were just reset and get a random start position"""
-        if not self.sample_board or not bool(mask.any()):
+        if not self.sample_board:
             return None
         boards = sample_boards(self.board_size, self.num_envs, self._gen, self.device)
         return self.vec.set_boards(boards, mask)
 
-    def _play_opponents(self, obs, legal, pending, handled):
-        """replies and openings until no board is pending; `handled` marks the boards whose end of
-        episode (new position, new opponent) has been dealt with already"""
-        while bool(pending.any()):
-            opening = pending == 2       # fresh boards: pick their opponent first (:75 before :79-80)
-            if bool(opening.any()):
-                self._setup_opponents(torch.nonzero(opening, as_tuple=False).squeeze(1))
-            self._opponent_actions(obs, legal, pending)
-            out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
-            obs, legal, pending = out[0], out[3], out[5]
-            fresh = (self.vec.done != 0) & ~handled
-            handled |= fresh
-            new = self._new_positions(fresh)
-            if new is not None:
-                obs, legal, pending = new
-        return handled
+    def _opponent_round(self, obs, legal, pending, handled, redraw=True):
+        """one round of opponent plies (replies, or openings of freshly reset boards)"""
+        if redraw:
+            self._setup_opponents(pending == 2)      # fresh boards pick their opponent first (:75, :79-80)
+        self._opponent_actions(obs, legal, pending)
+        out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+        obs, legal, pending = out[0], out[3], out[5]
+        fresh = (self.vec.done != 0) & ~handled
+        handled = handled | fresh
+        new = self._new_positions(fresh)
+        if new is not None:
+            obs, legal, pending = new
+        return obs, legal, pending, handled
 
     # -- gym-like API ----------------------------------------------------------
     def reset(self):
         """SelfPlayEnv.reset for every board (:69-89): new opponent, then it opens where the agent
         is WHITE."""
-        every = torch.arange(self.num_envs, device=self.device)
+        every = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
+        self._draw_candidates()
         self._setup_opponents(every)
         n = self.board_size
         if self.sample_board:            # positions first, then the openings through the split step
-            obs, legal, pending = self._new_positions(torch.ones(self.num_envs, dtype=torch.bool,
-                                                                 device=self.device))
+            obs, legal, pending = self._new_positions(every)
             self.vec.done.zero_()
-            handled = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
-            slots = self.slot.clone()
-            self._play_opponents(obs, legal, pending, handled)
-            self.slot.copy_(slots)       # the opening was played by the opponent chosen above
+            self._opponent_round(obs, legal, pending, every, redraw=False)   # openings, by the opponents chosen above
             return self.vec.obs, self.vec.legal
         # the opponent's view of the empty board is all zeros: its opening is computed up front
         empty = torch.zeros((self.num_envs, n, n), dtype=torch.int8, device=self.device)
         full = torch.ones((self.num_envs, n * n), dtype=torch.uint8, device=self.device)
-        self._opponent_actions(empty, full, self.vec.agent_colours() != 0)
+        self._opponent_actions(empty, full, self._white)
         return self.vec.reset(opp_actions=self._opp)
 
     def step(self, actions):
         """actions int [E] (agent's view) -> obs, reward, done, legal, winner.
 
         Finished boards are reset (with a fresh random position if sample_board); their opponent is
-        re-drawn before it opens (if it opens)."""
+        re-drawn before it opens (if it opens).  No host synchronisation: the number of opponent
+        rounds is fixed (replies, then openings if any agent plays WHITE)."""
         self.vec.done.zero_()        # the split calls write only the boards whose step completes
+        self._draw_candidates()
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
-        handled = self.vec.done != 0                   # ended on the agent's ply
-        ended1 = handled.clone()
+        ended1 = self.vec.done != 0                    # ended on the agent's ply
+        handled = ended1
         new = self._new_positions(ended1)
         if new is not None:
             obs, legal, pending = new
-        no_opening = ended1 & (pending == 0)           # BLACK agents: a new episode, a new opponent
-        if bool(no_opening.any()):
-            self._setup_opponents(torch.nonzero(no_opening, as_tuple=False).squeeze(1))
-        self._play_opponents(obs, legal, pending, handled)   # replies; re-draw + openings inside
-        ended2 = (self.vec.done != 0) & ~ended1 & (self.vec.agent_colours() == 0)
-        if bool(ended2.any()):
-            self._setup_opponents(torch.nonzero(ended2, as_tuple=False).squeeze(1))
+        self._setup_opponents(ended1 & (pending == 0))  # BLACK agents: a new episode, a new opponent
+        obs, legal, pending, handled = self._opponent_round(obs, legal, pending, handled)   # replies
+        if self._any_white:
+            obs, legal, pending, handled = self._opponent_round(obs, legal, pending, handled)   # openings
+        self._setup_opponents((self.vec.done != 0) & ~ended1 & ~self._white)
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
     def legal_actions(self):
@@ -288,6 +300,7 @@ class VecSelfPlayEnv:
 
     # -- buffer API (SelfplayWrapper.py:106-144) -------------------------------
     def set_eval(self, eval_state):
+        self._eval_cursor = torch.zeros((), dtype=torch.long, device=self.device)
         self.buffer.set_eval(eval_state)
 
     def get_scores(self):
