@@ -29,16 +29,16 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 HBM_COPY_GBPS = 6290.0
 
 
-def cpu_baseline(board, seconds=12.0):
+def cpu_baseline(board, seconds=12.0, cores=None):
     """The oracle (a C port of the reference algorithm) on this host's cores, same workload,
     run in chunks until `seconds` of CPU work have been timed."""
     from oracle import hex_oracle as ho
-    cores = os.cpu_count() or 1
-    E = 4096
+    cores = cores or os.cpu_count() or 1
+    E = 4096 if cores > 1 else 256
     o = ho.OracleVec(board, E, seed=0, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
     o.set_threads(cores)
     o.step_repeat(50)                      # thread start-up, page faults
-    K, chunk = 0, 2000
+    K, chunk = 0, 2000 if cores > 1 else 500
     t0 = time.perf_counter()
     while True:
         o.step_repeat(chunk)
@@ -208,6 +208,7 @@ def main():
         line.update(extra)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(N)
+            line["cpu_baseline_1thread"] = cpu_baseline(N, seconds=3.0, cores=1)
         print(json.dumps(line), flush=True)
     if under_launcher:
         dist.barrier()
