@@ -426,6 +426,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     const bool vec_ok = ((size_t)a.E * C) % 16 == 0;
     // the helper wave copies whole aligned blocks; tail blocks / unaligned rows stay on wave 0
     const bool helper_on = HELPER && (a.obs || a.legal) && vec_ok && nlive == BPW;
+    if (HELPER && wave == 0) __builtin_amdgcn_s_setprio(2); // the playing wave is the critical path
     if (HELPER && wave == 1) {
         if (helper_on) {
             for (int t = 0; t < a.T; ++t) { // one emission per step (a.T == 1 outside the rollouts)
