@@ -360,8 +360,10 @@ template <int N, int ENC, int BPW> struct Lpb {
             uint4 o, l;
             merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], B ? sn.r1[it] : sn.r0[it], o, l);
             if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
-                if (OBS) *reinterpret_cast<uint4 *>(obs + byte0) = o;
-                if (LEGAL) *reinterpret_cast<uint4 *>(legal + byte0) = l;
+                // streamed once, never re-read by this kernel: non-temporal stores
+                typedef u32 __attribute__((ext_vector_type(4))) v4u;
+                if (OBS) __builtin_nontemporal_store(v4u{o.x, o.y, o.z, o.w}, reinterpret_cast<v4u *>(obs + byte0));
+                if (LEGAL) __builtin_nontemporal_store(v4u{l.x, l.y, l.z, l.w}, reinterpret_cast<v4u *>(legal + byte0));
             }
         }
     }
