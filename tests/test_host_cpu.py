@@ -110,3 +110,18 @@ def test_oracle_rng_spec():
     empties = np.flatnonzero(view == 0)
     for r in (0, 2 ** 31, 2 ** 32 - 1, 123456789):
         assert L.hexo_uniform_legal(p, 9, 0, r) == empties[(r * len(empties)) >> 32]
+
+
+def test_minihex_alias_package_has_the_reference_module_names():
+    import hex_gym_env_amd.minihex as m
+    from hex_gym_env_amd.minihex.HexGame import HexEnv as EnvA, HexGame, player
+    from hex_gym_env_amd.minihex.HexSingleGame import HexEnv as EnvB
+    from hex_gym_env_amd.minihex.SelfplayWrapper import BaseRandomPolicy, OpponentPolicy, selfplay_wrapper
+    assert (player.BLACK, player.WHITE, player.EMPTY) == (0, 1, 2)
+    board = 2 * np.ones((3, 3))
+    board[1, 1] = 0
+    import random
+    random.seed(1)
+    assert m.random_policy(board) != 4                     # never the occupied cell
+    assert callable(selfplay_wrapper) and BaseRandomPolicy().save_model("x") is None
+    assert EnvA is not EnvB and HexGame is not None and OpponentPolicy is not None
