@@ -373,3 +373,28 @@ def test_entry_points_reject_wrong_handle_modes(hx):
             fn()
     assert fastsp.get_state()[1] is None and exact.get_state()[1] is not None
     assert fastsp.rollout_selfplay(0, out={}) == {}                # T = 0 is a no-op
+
+
+def test_steps_can_be_captured_in_a_hip_graph(hx):
+    """the ABI enqueues on the caller's stream and never synchronises, so a launch-bound loop of
+    steps can be captured once (torch.cuda.CUDAGraph = hipGraph) and replayed; results == oracle"""
+    n, E, K = 7, 128, 8
+    env = hx.HexVecEnv(n, E, encoding="B", seed=3)
+    ref = ho.OracleVec(n, E, seed=3, flags=ho.F_ENC_B | ho.F_AGENT_RANDOM)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        env.step()                                   # warm-up outside the capture
+        ref.step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(K):
+                env.step()                           # K device-drawn self-play steps per replay
+    for rep in range(5):
+        graph.replay()
+        torch.cuda.synchronize()
+        for _ in range(K):
+            oo, ol, orw, od, ow = ref.step()
+        assert np.array_equal(_np(env.obs).reshape(E, -1), oo), rep
+        assert np.array_equal(_np(env.reward), orw) and np.array_equal(_np(env.done), od), rep
+    assert np.array_equal(_np(env.episode_stats()), ref.episode_stats())
