@@ -130,14 +130,20 @@ def main():
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE is half-counted on gfx950, MI355X_MICROARCH.md HBM section); null if the
     # profile was taken for another configuration
-    traffic = None
+    traffic, on_chip = None, None
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.json")))
         if (prof["config"] == {"board": N, "envs": E, "steps_per_launch": T}
                 and main_kernel.endswith("rollout1>")):
             traffic = (2 * prof["FETCH_SIZE_KiB"] + prof["WRITE_SIZE_KiB"]) * 1024.0
+            c = prof["counters"]["rollout1"]
+            glob_insts = c["SQ_INSTS_VMEM_RD"] + c["SQ_INSTS_VMEM_WR"]
+            on_chip = {"lds_insts_per_launch": c["SQ_INSTS_LDS"], "global_insts_per_launch": glob_insts,
+                       "lds_share_of_memory_insts": c["SQ_INSTS_LDS"] / (c["SQ_INSTS_LDS"] + glob_insts),
+                       "lds_bank_conflict_cycle_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
+                       "source": "profiles/r01/bench_pmc_summary.json (rocprofv3 --pmc, same command)"}
     except Exception:
-        traffic = None
+        traffic, on_chip = None, None
 
     extra = {}
     if not args.no_host_stepped:
@@ -206,6 +212,8 @@ def main():
                          "agent_wins": stats[3]},
         }
         line.update(extra)
+        if on_chip:
+            line["on_chip"] = on_chip
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(N)
             line["cpu_baseline_1thread"] = cpu_baseline(N, seconds=3.0, cores=1)
