@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--chunk", type=int, default=200, help="env steps per rollout launch")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-host-stepped", action="store_true")
     args = ap.parse_args()
 
@@ -215,8 +216,8 @@ def main():
         if on_chip:
             line["on_chip"] = on_chip
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(N)
-            line["cpu_baseline_1thread"] = cpu_baseline(N, seconds=3.0, cores=1)
+            line["cpu_baseline"] = cpu_baseline(N, seconds=args.cpu_seconds)
+            line["cpu_baseline_1thread"] = cpu_baseline(N, seconds=min(3.0, args.cpu_seconds), cores=1)
         print(json.dumps(line), flush=True)
     if under_launcher:
         dist.barrier()

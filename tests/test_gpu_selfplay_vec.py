@@ -398,3 +398,28 @@ def test_steps_can_be_captured_in_a_hip_graph(hx):
         assert np.array_equal(_np(env.obs).reshape(E, -1), oo), rep
         assert np.array_equal(_np(env.reward), orw) and np.array_equal(_np(env.done), od), rep
     assert np.array_equal(_np(env.episode_stats()), ref.episode_stats())
+
+
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the contract's keys, a roofline and a cpu_baseline object"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "10",
+                          "--envs", "8192", "--chunk", "20", "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 10 and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(d["value"] - 8192 * 40 / (d["ms_per_step"] * 40e-3)) / d["value"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
