@@ -58,6 +58,17 @@ def sample_boards(board_size, count, generator, device):
     return board.view(count, n, n)
 
 
+def sample_masked(logits, legal, generator=None):
+    """One categorical sample per row from softmax(logits) restricted to legal != 0, by the Gumbel-max
+    trick: argmax(logits + G).  Same distribution as multinomial(softmax(masked logits)) but without
+    torch.multinomial's device-side assertion, so it can be captured in a hipGraph and a degenerate
+    row (no legal cell) yields action 0 instead of trapping the GPU."""
+    u = torch.rand(logits.shape, generator=generator, device=logits.device, dtype=torch.float32)
+    g = -torch.log(-torch.log(u.clamp_(1e-20, 1.0 - 1e-7)))
+    z = torch.where(legal != 0, logits.float() + g, torch.full_like(g, float("-inf")))
+    return z.argmax(1)
+
+
 class RandomLegalPolicy:
     """uniform over the empty cells, drawn with torch's generator on the device"""
 
@@ -65,7 +76,7 @@ class RandomLegalPolicy:
         self.generator = generator
 
     def choose_actions(self, obs, legal):
-        return torch.multinomial(legal.float(), 1, generator=self.generator).squeeze(1)
+        return sample_masked(torch.zeros(legal.shape, device=legal.device), legal, self.generator)
 
     def save_model(self, path):
         return None
@@ -121,10 +132,10 @@ class MlpActorPolicy(torch.nn.Module):
 
     @torch.no_grad()
     def choose_actions(self, obs, legal):
-        z = self.logits(obs, legal)
         if self.deterministic:
-            return z.argmax(1)
-        return torch.multinomial(torch.softmax(z, 1), 1, generator=self.generator).squeeze(1)
+            return self.logits(obs, legal).argmax(1)
+        x = obs.reshape(obs.shape[0], -1).float()
+        return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator)
 
     def save_model(self, path):
         torch.save(self.state_dict(), path)
@@ -209,10 +220,10 @@ class VecSelfPlayEnv:
         if self.buffer.evaluating:       # walk the pool in order, one member per new episode
             rank = torch.cumsum(mask.to(torch.long), 0) - 1
             new = (rank + self._eval_cursor) % len(self.buffer)
-            self._eval_cursor = self._eval_cursor + mask.sum()      # device-side cursor
+            self._eval_cursor.add_(mask.sum())                      # device-side cursor, in place
         else:
             new = self._cand
-        self.slot = torch.where(mask, new, self.slot)
+        self.slot.copy_(torch.where(mask, new, self.slot))         # in place: hipGraph replays read this tensor
 
     def _opponent_actions(self, obs, legal, pending):
         """actions of every pending board's opponent.  Boards are grouped by distinct policy OBJECT
@@ -226,13 +237,13 @@ class VecSelfPlayEnv:
         for pol, slots in groups.values():
             a = pol.choose_actions(obs, safe_legal).to(torch.int32)
             if first and len(groups) == 1:
-                self._opp = a
+                self._opp.copy_(a)
                 return
             first = False
             member = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
             for k in slots:
                 member |= self.slot == k
-            self._opp = torch.where(member, a, self._opp)
+            self._opp.copy_(torch.where(member, a, self._opp))
 
     def _new_positions(self, mask):
         """sample_board: the boards in `mask` were just reset and get a random start position"""
@@ -295,12 +306,46 @@ class VecSelfPlayEnv:
         self._setup_opponents((self.vec.done != 0) & ~ended1 & ~self._white)
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
+    def capture_collect_step(self, agent_policy, warmup=3):
+        """Capture  actions = agent_policy.choose_actions(obs, legal); step(actions)  as ONE hipGraph
+        (torch.cuda.CUDAGraph).  step() never synchronises and all shapes are static, so the ~40 small
+        launches of a collection step replay with a single host call.  Returns run() -> (obs, reward,
+        done, legal, winner, actions); the tensors are static buffers overwritten by every run().
+        The policies must be capturable (no host synchronisation, default or registered generators)."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        holder = {}
+
+        def body():
+            a = agent_policy.choose_actions(self.vec.obs, self.vec.legal)
+            holder["actions"] = a
+            self.step(a)
+
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                body()
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            if hasattr(graph, "register_generator_state"):
+                graph.register_generator_state(self._gen)
+            with torch.cuda.graph(graph, stream=side):
+                body()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self._graph = graph
+
+        def run():
+            graph.replay()
+            return (self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner,
+                    holder["actions"])
+
+        return run
+
     def legal_actions(self):
         return self.vec.legal
 
     # -- buffer API (SelfplayWrapper.py:106-144) -------------------------------
     def set_eval(self, eval_state):
-        self._eval_cursor = torch.zeros((), dtype=torch.long, device=self.device)
+        self._eval_cursor.zero_()
         self.buffer.set_eval(eval_state)
 
     def get_scores(self):

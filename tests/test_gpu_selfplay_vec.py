@@ -423,3 +423,25 @@ def test_bench_json_contract():
     assert abs(d["value"] - 8192 * 40 / (d["ms_per_step"] * 40e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_collect_step_as_one_hip_graph(hx):
+    """policy forward + env step + opponent networks captured once and replayed; invariants hold"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    n, E = 7, 2048
+    torch.manual_seed(0)
+    agent, opp = MlpActorPolicy(n * n).to("cuda"), MlpActorPolicy(n * n).to("cuda")
+    env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=5, base_model=opp, seed=4)
+    env.reset()
+    col = env.vec.agent_colours()
+    run = env.capture_collect_step(agent)
+    before = _np(env.episode_stats())[2]
+    tot = 0
+    for k in range(40):
+        obs, rew, done, legal, win, act = run()
+        o = obs.reshape(E, -1)
+        assert torch.equal(legal, (o == 0).to(torch.uint8))
+        own, other = (o == -1).sum(1), (o == 1).sum(1)
+        assert torch.equal(own, torch.where(col == 0, other, other - 1))
+        tot += int(done.sum())
+    assert tot > E and _np(env.episode_stats())[2] - before == tot

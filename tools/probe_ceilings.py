@@ -67,6 +67,17 @@ tb = ev_time(both, 50)
 print("config 3 (7x7, %d envs): agent policy forward+sample %.1f us; full collection step %.1f us "
       "(env incl. ~2 opponent-policy calls %.1f us) -> %.2f M agent steps/s" %
       (E, tp * 1e6, tb * 1e6, (tb - tp) * 1e6, E / tb / 1e6))
+run = env.capture_collect_step(agent)
+bad_rows = torch.zeros((), dtype=torch.long, device=dev)
+illegal = torch.zeros((), dtype=torch.long, device=dev)
+for _ in range(100):                      # diagnostics on the replayed graph, no device-side asserts anywhere
+    obs_, rew_, done_, legal_, win_, act_ = run()
+    bad_rows += (legal_.sum(1) == 0).sum()
+    illegal += (win_ == 3).sum()
+print("  graph replay diagnostics over 100 steps: rows without a legal cell %d, illegal-move endings %d"
+      % (int(bad_rows), int(illegal)))
+tg = ev_time(run, 200)
+print("  the same collection step captured as one hipGraph: %.1f us -> %.2f M agent steps/s" % (tg * 1e6, E / tg / 1e6))
 raw = env.vec
 a32 = state["a"].to(torch.int32)
 tr = ev_time(lambda: raw.step(a32), 200)
