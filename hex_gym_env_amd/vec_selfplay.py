@@ -196,6 +196,8 @@ class VecSelfPlayEnv:
         self._white = self.vec.agent_colours() != 0       # fixed per board (SelfplayWrapper.py:72-73)
         self._any_white = bool(self._white.any())          # one host read, at construction
         self._eval_cursor = torch.zeros((), dtype=torch.long, device=self.device)
+        self._empty_board = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8, device=self.device)
+        self._all_legal = torch.ones((num_envs, board_size * board_size), dtype=torch.uint8, device=self.device)
 
     # the reference's attribute names
     opponent_models = property(lambda self: self.buffer.members)
@@ -245,6 +247,28 @@ class VecSelfPlayEnv:
                 member |= self.slot == k
             self._opp.copy_(torch.where(member, a, self._opp))
 
+    def _opening_actions(self):
+        """openings on EMPTY boards: every board that shares a policy has the same distribution, so a
+        policy exposing logits() is evaluated on one empty board and sampled once per board"""
+        n, E = self.board_size, self.num_envs
+        groups = {}
+        for k in range(-1, len(self.buffer)):
+            groups.setdefault(id(self.buffer.policy(k)), (self.buffer.policy(k), []))[1].append(k)
+        full = self._all_legal
+        for pol, slots in groups.values():
+            if hasattr(pol, "logits"):
+                z = pol.logits(self._empty_board[:1], full[:1])
+                a = sample_masked(z.expand(E, -1), full, getattr(pol, "generator", None)).to(torch.int32)
+            else:
+                a = pol.choose_actions(self._empty_board, full).to(torch.int32)
+            if len(groups) == 1:
+                self._opp.copy_(a)
+                return
+            member = torch.zeros(E, dtype=torch.bool, device=self.device)
+            for k in slots:
+                member |= self.slot == k
+            self._opp.copy_(torch.where(member, a, self._opp))
+
     def _new_positions(self, mask):
         """sample_board: the boards in `mask` were just reset and get a random start position"""
         if not self.sample_board:
@@ -252,11 +276,14 @@ class VecSelfPlayEnv:
         boards = sample_boards(self.board_size, self.num_envs, self._gen, self.device)
         return self.vec.set_boards(boards, mask)
 
-    def _opponent_round(self, obs, legal, pending, handled, redraw=True):
+    def _opponent_round(self, obs, legal, pending, handled, redraw=True, openings_only=False):
         """one round of opponent plies (replies, or openings of freshly reset boards)"""
         if redraw:
             self._setup_opponents(pending == 2)      # fresh boards pick their opponent first (:75, :79-80)
-        self._opponent_actions(obs, legal, pending)
+        if openings_only and not self.sample_board:
+            self._opening_actions()                  # only empty boards can be pending here
+        else:
+            self._opponent_actions(obs, legal, pending)
         out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
         obs, legal, pending = out[0], out[3], out[5]
         fresh = (self.vec.done != 0) & ~handled
@@ -280,9 +307,7 @@ class VecSelfPlayEnv:
             self._opponent_round(obs, legal, pending, every, redraw=False)   # openings, by the opponents chosen above
             return self.vec.obs, self.vec.legal
         # the opponent's view of the empty board is all zeros: its opening is computed up front
-        empty = torch.zeros((self.num_envs, n, n), dtype=torch.int8, device=self.device)
-        full = torch.ones((self.num_envs, n * n), dtype=torch.uint8, device=self.device)
-        self._opponent_actions(empty, full, self._white)
+        self._opening_actions()
         return self.vec.reset(opp_actions=self._opp)
 
     def step(self, actions):
@@ -302,7 +327,8 @@ class VecSelfPlayEnv:
         self._setup_opponents(ended1 & (pending == 0))  # BLACK agents: a new episode, a new opponent
         obs, legal, pending, handled = self._opponent_round(obs, legal, pending, handled)   # replies
         if self._any_white:
-            obs, legal, pending, handled = self._opponent_round(obs, legal, pending, handled)   # openings
+            obs, legal, pending, handled = self._opponent_round(obs, legal, pending, handled,
+                                                                 openings_only=True)   # openings
         self._setup_opponents((self.vec.done != 0) & ~ended1 & ~self._white)
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
