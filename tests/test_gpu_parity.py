@@ -447,3 +447,30 @@ def test_soak_two_sided_rollout_long(hx):
         assert np.array_equal(_np(out["done"]), odone), launch
         assert np.array_equal(_np(out["obs"][-1]), oobs[-1]), launch
     _same_state(g, o)
+
+
+@pytest.mark.parametrize("enc", ["A", "B"])
+def test_out_of_range_actions_are_illegal_plies_on_both_families(hx, enc):
+    """the reference would raise (or wrap) on an out-of-board index; the ABI defines it as an illegal
+    ply: done, reward 0 (env B / self-play) or -100 (hex-v0), winner code 3 -- same on both families"""
+    n, E = 6, 128
+    bad = np.array([-1, -7, n * n, n * n + 1, 10 ** 6, -2 ** 31, 2 ** 31 - 1, 255], np.int32)
+    rng = np.random.default_rng(3)
+    fast = hx.HexVecEnv(n, E, encoding=enc, seed=5)
+    exact = hx.HexVecEnv(n, E, encoding=enc, seed=5, exact_labels=True)
+    for k in range(12):
+        a = rng.integers(0, n * n, size=E).astype(np.int32)
+        idx = rng.choice(E, size=16, replace=False)
+        a[idx] = rng.choice(bad, size=16)
+        fo = [x.clone() for x in fast.step(a)]
+        eo = exact.step(a)
+        for x, y in zip(fo, eo):
+            assert torch.equal(x, y), k
+        rew, done, win = _np(fo[1]), _np(fo[2]), _np(fo[4])
+        assert (done[idx] == 1).all() and (win[idx] == 3).all()
+        assert (rew[idx] == (-100 if enc == "A" else 0)).all()
+    two_f = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=6)
+    two_e = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=6, exact_labels=True)
+    a = np.full(E, -3, np.int32)
+    for x, y in zip([t.clone() for t in two_f.step(a)], two_e.step(a)):
+        assert torch.equal(x, y)
