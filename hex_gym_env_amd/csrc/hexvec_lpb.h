@@ -549,6 +549,30 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.winner = ply(oa, 1, check); // hex-v0: the opponent's view is the transposed frame
         return 0;
     };
+    // The same opponent ply on a board that is known to be EMPTY (just reset inside this kernel):
+    // the k-th empty cell is cell k and the stone has no neighbours, so there is nothing to search,
+    // chase or union -- one root byte, two image bytes, two bitboard bits.
+    auto opening_on_empty = [&]() {
+        const u32 r = L::draw(s);
+        const int act = (int)__umulhi(r, (u32)C); // n_empty == C
+        const int p = s.cur, fr = B ? p : 1;      // B: the mover's frame; hex-v0: the opponent's view
+        const int yf = act / N, xf = act - yf * N, at = xf * N + yf;
+        const int idx0 = fr ? at : act, idx1 = fr ? act : at;
+        L::clear_bit(s.E0, idx0);
+        L::clear_bit(s.E1, idx1);
+        s.n_empty -= 1;
+        if (B) {
+            lds[L::IMG + lane * C + idx0] = p ? 1 : 0xFF;
+            lds[L::IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;
+        } else {
+            lds[L::IMG + lane * C + idx0] = (unsigned char)p;
+        }
+        const int yp = p == fr ? yf : xf; // row of the stone in p's own frame
+        lds[(p * BPW + lane) * L::PS + (p ? idx1 : idx0)] =
+            (unsigned char)(0xE0u | (yp == 0 ? 1u : 0u) | (yp == N - 1 ? 2u : 0u));
+        s.winner = -1; // make_move returned None
+        s.cur = p ^ 1;
+    };
     const bool opens = selfplay && (B ? s.agent != 0 : first != 0); // the opponent moves first after a reset
     // wave-level: finished boards -> terminal obs, statistics, fresh board.  `won` per lane.
     auto handle_done = [&](bool dn, int won, signed char *tobs_row) {
@@ -725,7 +749,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 const bool dn2 = reply && s.done;
                 handle_done(dn2, won, tobs_row);
                 // ---- slot 3: openings of the boards that ended on the reply
-                if (dn2 && opens) opponent_ply(L::rng_action(s, B ? s.cur : 1), false);
+                if (dn2 && opens) opening_on_empty();
             }
             if (live) {
                 if (a.reward) a.reward[o] = (float)rew;
