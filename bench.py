@@ -54,8 +54,8 @@ def cpu_baseline(board, seconds=12.0, cores=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--board", type=int, default=11)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--chunk", type=int, default=200, help="env steps per rollout launch")
