@@ -362,6 +362,24 @@ def export_actor_weights(zip_path, out_path):
     np.savez_compressed(out_path, **keep)
 
 
+def gen_config1(HexGameA, playerA, random_policy, n=5, games=1000):
+    """BASELINE config 1: 5x5, reference CPU HexGame, python-`random` policy (seed 0) for both sides;
+    per game the action sequence and the make_move return codes (compact)"""
+    random.seed(0)
+    T = n * n
+    acts = np.full((games, T), -1, np.int8)
+    rets = np.full((games, T), -2, np.int8)
+    for g in range(games):
+        sim = HexGameA(playerA.BLACK, playerA.EMPTY * np.ones((n, n)), playerA.BLACK)
+        t = 0
+        while not sim.done:
+            a = random_policy(sim.board)
+            w = sim.make_move(a)
+            acts[g, t], rets[g, t] = a, _ret_code(w)
+            t += 1
+    return {"n": np.int32(n), "actions": acts, "ret": rets}
+
+
 def gen_render(HexEnvA, playerA, HexEnvB, random_policy):
     texts = {}
     for n in (3, 5):
@@ -413,6 +431,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "preplaced.npz"),
                         **gen_preplaced(HexGameA, playerA, HexGameB, [3, 5, 7, 11], rng))
     np.savez_compressed(os.path.join(OUT, "sample_board.npz"), **gen_sample_board(HexEnvB, [5, 7, 11]))
+    np.savez_compressed(os.path.join(OUT, "config1_5x5.npz"), **gen_config1(HexGameA, playerA, random_policy))
     export_actor_weights(os.path.join(REF, "models", "5x5_MLP-default_lr-0.0003_31"),
                          os.path.join(OUT, "sb3_5x5_actor.npz"))
     for name, (board, text) in gen_render(HexEnvA, playerA, HexEnvB, random_policy).items():

@@ -474,3 +474,21 @@ def test_out_of_range_actions_are_illegal_plies_on_both_families(hx, enc):
     a = np.full(E, -3, np.int32)
     for x, y in zip([t.clone() for t in two_f.step(a)], two_e.step(a)):
         assert torch.equal(x, y)
+
+
+def test_config1_thousand_reference_games_5x5(hx):
+    """BASELINE config 1 on the GPU: the 1 000 reference games replayed as 1 000 envs"""
+    d = np.load(os.path.join(GOLDEN, "config1_5x5.npz"))
+    n, acts, rets = int(d["n"]), d["actions"].astype(np.int32), d["ret"]
+    G, T = acts.shape
+    env = hx.HexVecEnv(n, G, encoding="A", two_sided=True, auto_reset=False)
+    ret, done, _, legal, obs = (_np(x) for x in env.apply_moves(np.ascontiguousarray(acts.T)))
+    played = acts.T >= 0
+    assert np.array_equal(ret[played], rets.T[played])
+    last = played.sum(0) - 1
+    assert (done[last, np.arange(G)] == 1).all() and (done[0] == 0).all()
+    # and through the single-ply step of the lane-per-board kernels (auto reset on the winning ply)
+    fast = hx.HexVecEnv(n, G, encoding="A", two_sided=True)
+    for t in range(int(last.min()) + 1):
+        o, r, dn, lg, w = fast.step(acts[:, t])
+        assert np.array_equal(_np(w), rets[:, t]), t

@@ -181,3 +181,22 @@ def test_winner_is_plain_connectivity():
                 assert (ret == mover) == win
                 if win:
                     break
+
+
+def test_config1_thousand_games_5x5():
+    """BASELINE config 1: 1 000 reference games at 5x5 (python-random policy, seed 0): the oracle
+    returns the same make_move code on every ply and ends on the same ply with the same winner"""
+    L, d = ho.lib(), _load("config1_5x5.npz")
+    n, acts, rets = int(d["n"]), d["actions"], d["ret"]
+    wins = [0, 0]
+    for g in range(acts.shape[0]):
+        sim = ho.Game()
+        L.hexo_game_init(C.byref(sim), n, ho.ENC_A, 0, None)
+        for t in range(acts.shape[1]):
+            if acts[g, t] < 0:
+                break
+            assert L.hexo_make_move(C.byref(sim), int(acts[g, t])) == rets[g, t], (g, t)
+        last = int((acts[g] >= 0).sum()) - 1
+        assert sim.done and rets[g, last] in (0, 1)
+        wins[int(rets[g, last])] += 1
+    assert sum(wins) == 1000 and wins[0] > wins[1]          # the first mover wins more often
