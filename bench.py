@@ -169,7 +169,7 @@ def main():
                     actions=torch.empty((T2, E), dtype=torch.int32, device=dev),
                     reward=torch.empty((T2, E), dtype=torch.float32, device=dev),
                     done=torch.empty((T2, E), dtype=torch.uint8, device=dev))
-        for _ in range(10):
+        for _ in range(60):                      # ~12 ms: past the clock ramp after start-up
             env2.rollout_random(T2, out2)
         fence()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
