@@ -1,6 +1,7 @@
 // hexvec.hip -- host side of libhexvec: the C ABI of include/hexvec.h.
-// Kernels: hexvec_wpb.hip (wave-per-board, literal engine), hexvec_lpb64.hip /
-// hexvec_lpb32.hip (lane-per-board, throughput path; hexvec_lpb.h).
+// Kernels: hexvec_wpb.hip (wave-per-board, literal engine), hexvec_qpb_{s,m,l}.hip (lanes-per-board
+// bitboards, the throughput path; hexvec_qpb.h), hexvec_lpb64.hip / hexvec_lpb32.hip (lane-per-board
+// union-find in LDS, the round-1 throughput path, kept selectable with HEXVEC_FAMILY=lpb for A/B runs).
 #include <stdlib.h>
 
 #include "hexvec_common.h"
@@ -15,8 +16,9 @@ struct hexvec {
     hv::u32 *planes;
     hv::u32 *hot;
     int *stats;
-    bool fast_mode;      // lane-per-board kernels + fast state (auto-reset handles)
-    int bpw;             // boards per wavefront of the fast kernels (64 or 32)
+    bool fast_mode;      // throughput kernels + fast state (auto-reset handles)
+    bool qpb;            // fast_mode: bitboard kernels (hexvec_qpb.h); else the LDS union-find ones (hexvec_lpb.h)
+    int bpw;             // lpb: boards per wavefront (64 or 32)
     unsigned char *fast;
     size_t fast_bytes;
 };
@@ -99,11 +101,28 @@ static const char *lpb_kname(int mode)
     }
 }
 
+static const char *qpb_kname(int mode)
+{
+    switch (mode) {
+    case M_ROLLOUT2: return "k_qpb<rollout2>";
+    case M_STEP: return "k_qpb<step>";
+    case M_ROLLOUT1: return "k_qpb<rollout1>";
+    case M_SETBOARD: return "k_qpb<set_boards>";
+    default: return "k_qpb<reset>";
+    }
+}
+// the translation unit that holds board size N
+#define HV_QPB_CALL(N, fn, ...) \
+    ((N) <= 8 ? hv::qpb_s_##fn(__VA_ARGS__) : (N) <= 11 ? hv::qpb_m_##fn(__VA_ARGS__) : hv::qpb_l_##fn(__VA_ARGS__))
+
 static int run(hexvec *h, int mode, const KArgs &a, void *stream)
 {
     HV_DEVICE(h);
     const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
-    if (h->fast_mode) {
+    if (h->fast_mode && h->qpb) {
+        g_kernel = qpb_kname(mode);
+        HV_HIP(HV_QPB_CALL(h->N, launch, h->N, enc, mode, a, (hipStream_t)stream));
+    } else if (h->fast_mode) {
         g_kernel = lpb_kname(mode);
         HV_HIP(h->bpw == 32 ? lpb32_launch(h->N, enc, mode, a, (hipStream_t)stream)
                             : lpb64_launch(h->N, enc, mode, a, (hipStream_t)stream));
@@ -153,7 +172,14 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     // measured within 2 % of it on MI355X and stays selectable for experiments
     h->bpw = 64;
     if (const char *ev = getenv("HEXVEC_BPW")) h->bpw = atoi(ev) == 32 ? 32 : (atoi(ev) == 64 ? 64 : h->bpw);
-    if (h->fast_mode) {
+    h->qpb = true;
+    if (const char *ev = getenv("HEXVEC_FAMILY")) h->qpb = strcmp(ev, "lpb") != 0;
+    if (h->fast_mode && h->qpb) {
+        const int bpw = 64 / hv::qpb_lanes(board_size);
+        const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 16;
+        h->fast_bytes = bytes;
+        ok = hipMalloc(&h->fast, bytes) == hipSuccess;
+    } else if (h->fast_mode) {
         const int enc = (flags & HEXVEC_F_ENC_B) ? 1 : 0;
         const size_t bytes = h->bpw == 32
                                  ? (size_t)((num_envs + 31) / 32) * hv::lpb32_block_bytes(board_size, enc)
@@ -339,8 +365,14 @@ extern "C" int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uin
         if (labels)
             return fail(HEXVEC_E_MODE, "%s",
                         "label planes exist only on HEXVEC_F_EXACT_LABELS / NO_AUTO_RESET handles");
-        g_kernel = "k_lpb_get_state";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
+        if (h->qpb) {
+            g_kernel = "k_qpb_get_state";
+            HV_HIP(HV_QPB_CALL(h->N, get_state, h->fast, h->N, enc, h->E, (signed char *)board, cur_player,
+                               (hipStream_t)stream));
+            return HEXVEC_OK;
+        }
+        g_kernel = "k_lpb_get_state";
         HV_HIP(h->bpw == 32 ? hv::lpb32_get_state(h->fast, h->N, enc, h->E, (signed char *)board, cur_player, (hipStream_t)stream)
                             : hv::lpb64_get_state(h->fast, h->N, enc, h->E, (signed char *)board, cur_player, (hipStream_t)stream));
         return HEXVEC_OK;
@@ -388,6 +420,12 @@ extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)
     HV_HANDLE(h);
     if (!out4) return fail(HEXVEC_E_ARG, "%s", "out4 is NULL");
     HV_DEVICE(h);
+    if (h->fast_mode && h->qpb) {
+        g_kernel = "k_qpb_stats";
+        HV_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(double), (hipStream_t)stream));
+        HV_HIP(HV_QPB_CALL(h->N, stats, h->fast, h->N, h->E, out4, nullptr, (hipStream_t)stream));
+        return HEXVEC_OK;
+    }
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
@@ -405,6 +443,11 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
     HV_HANDLE(h);
     if (!out) return fail(HEXVEC_E_ARG, "%s", "out is NULL");
     HV_DEVICE(h);
+    if (h->fast_mode && h->qpb) {
+        g_kernel = "k_qpb_stats";
+        HV_HIP(HV_QPB_CALL(h->N, stats, h->fast, h->N, h->E, nullptr, out, (hipStream_t)stream));
+        return HEXVEC_OK;
+    }
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;

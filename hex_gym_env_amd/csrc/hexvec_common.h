@@ -96,4 +96,28 @@ hipError_t lpb32_get_state(const unsigned char *fast, int N, int enc, int E, sig
 hipError_t lpb32_stats(const unsigned char *fast, int N, int enc, int E, double *out4,
                        unsigned char *agents, hipStream_t st);
 
+
+// lanes-per-board bitboard kernels (hexvec_qpb.h), one translation unit per size range
+#define HV_QPB_DECL(x)                                                                                        \
+    hipError_t qpb_##x##_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);                    \
+    hipError_t qpb_##x##_get_state(const unsigned char *fast, int N, int enc, int E, signed char *board,      \
+                                   unsigned char *cur, hipStream_t st);                                       \
+    hipError_t qpb_##x##_stats(const unsigned char *fast, int N, int E, double *out4, unsigned char *agents,  \
+                               hipStream_t st);
+HV_QPB_DECL(s)
+HV_QPB_DECL(m)
+HV_QPB_DECL(l)
+#undef HV_QPB_DECL
+// geometry of that family (must match qpb::Geo<N>)
+inline int qpb_lanes(int N)
+{
+    const int jw = (N * N + 31) / 32;
+    return jw <= 1 ? 1 : jw <= 2 ? 2 : jw <= 4 ? 4 : jw <= 8 ? 8 : 16;
+}
+inline size_t qpb_block_bytes(int N)
+{
+    const int L = qpb_lanes(N);
+    return (size_t)(8 + (3 + L - 1) / L) * 64 * 4;
+}
+
 } // namespace hv

@@ -172,7 +172,7 @@ def _pair(hx, n, E, enc, two_sided=False, agent=None, auto_reset=True, first=0, 
                      auto_reset=auto_reset, first_player=first, seed=seed, env_offset=off,
                      exact_labels=exact)
     assert g.exact == (exact or not auto_reset or n < 4)
-    assert g.last_kernel().startswith("k_hex" if g.exact else "k_lpb")
+    assert g.last_kernel().startswith("k_hex" if g.exact else ("k_qpb", "k_lpb"))
     o = ho.OracleVec(n, E, seed=seed, flags=_flags(enc, two_sided, agent, auto_reset, first),
                      env_offset=off)
     return g, o
