@@ -5,10 +5,18 @@ Workload (BASELINE.json configs[1]): 11x11, 65 536 parallel envs per GPU,
 random policy.  One "step" = one SelfPlayEnv.step per env (agent ply +
 opponent reply + auto reset; SURVEY 8(d) unit W1), agent and opponent both
 uniform-legal, drawn on the device.  The timed region runs the K steps as
-launches of the device-resident self-play rollout kernel (k_hex<rollout1>,
-T steps per launch, every step's obs / mask / action / reward / done written
-to HBM); the host-stepped rate (one hexvec_step launch per step) is reported
-beside it.
+launches of the device-resident self-play rollout kernel (k_lpb<rollout1>,
+T = min(--chunk, K) steps per launch, every step's obs / mask / action /
+reward / done written to HBM); the host-stepped rate (one hexvec_step launch
+per step) is reported beside it.
+
+Timing: a fixed internal warm-up of rollout launches (>= 30 ms, the chip needs
+~10 ms of load to reach its clock; reported as warmup_internal_ms) precedes the
+--warmup steps.  The K-step region is then repeated `timed_reps` times back to
+back inside ONE barrier + synchronize bracket; every repetition is timed with
+HIP events on the launch stream.  ms_per_step is the MEDIAN repetition (max
+over ranks) / K and `value` follows from it; wall_ms_per_step (bracket wall
+time / all steps) is printed beside it as the cross-check.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -27,6 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_GBPS = 6290.0
+PROFILE_ROUND = "r02"       # profiles/<round>/bench_pmc_summary.json: the PMC passes of the driver's command
 
 
 def cpu_baseline(board, seconds=12.0, cores=None):
@@ -62,6 +71,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-host-stepped", action="store_true")
+    ap.add_argument("--no-w2", action="store_true", help="skip the two-sided rollout leg")
+    ap.add_argument("--layout", choices=["rollout", "bitboard"], default="rollout",
+                    help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT)")
+    ap.add_argument("--reps", type=int, default=0, help="timed repetitions of the --steps region (0 = auto, >= 20)")
+    ap.add_argument("--warmup-internal-ms", type=float, default=30.0)
     args = ap.parse_args()
 
     import torch
@@ -86,7 +100,10 @@ def main():
 
     N, E, T = args.board, args.envs, max(1, min(args.chunk, args.steps))
     C = N * N
-    env = hx.HexVecEnv(N, E, device=dev, encoding="B", seed=0, env_offset=rank * E)
+    # the rollout handle keeps its state in the rollout layout (HEXVEC_F_ROLLOUT_LAYOUT: lane-per-board
+    # union-find); --layout bitboard runs the same rollout on the default (host-stepping) layout
+    env = hx.HexVecEnv(N, E, device=dev, encoding="B", seed=0, env_offset=rank * E,
+                       rollout_layout=args.layout == "rollout")
     out = dict(obs=torch.empty((T, E, C), dtype=torch.int8, device=dev),
                legal=torch.empty((T, E, C), dtype=torch.uint8, device=dev),
                actions=torch.empty((T, E), dtype=torch.int32, device=dev),
@@ -108,61 +125,95 @@ def main():
         hxdist.barrier()
         torch.cuda.synchronize(dev)
 
+    # internal clock-ramp warm-up, independent of --warmup
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(8):
+            env.rollout_selfplay(T, out)
+        torch.cuda.synchronize(dev)
+        warm_ms = 1e3 * (time.perf_counter() - t0)
+        if warm_ms >= args.warmup_internal_ms:
+            break
     run_steps(args.warmup)
     main_kernel = env.last_kernel()
+    torch.cuda.synchronize(dev)
+    # size the repetition count from one probe region: >= 20 repetitions and >= ~60 ms of timed work
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launches_per_rep = run_steps(args.steps)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    reps = args.reps or int(min(2000, max(20, 60.0 / max(e0.elapsed_time(e1), 1e-3))))
+    reps = int(hxdist.max_over_ranks(reps, dev))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()            # libhexvec launches on torch's current stream, as do these events
-    launches = run_steps(args.steps)
-    ev1.record()
+    evs[0].record()         # libhexvec launches on torch's current stream, as do these events
+    for r in range(reps):
+        run_steps(args.steps)
+        evs[r + 1].record()
     fence()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1)        # HIP events around the timed launches
-    dt = hxdist.max_over_ranks(dt, dev)
-    value = world * E * args.steps / dt
+    wall = time.perf_counter() - t0
+    rep_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(reps))
+    med_ms = rep_ms[len(rep_ms) // 2] if reps % 2 else 0.5 * (rep_ms[reps // 2 - 1] + rep_ms[reps // 2])
+    med_ms = hxdist.max_over_ranks(med_ms, dev)
+    wall = hxdist.max_over_ranks(wall, dev)
+    ms_per_step = med_ms / args.steps
+    value = world * E / (ms_per_step * 1e-3)
 
     # the dominant kernel: bytes it must write per env step (obs + mask + action + reward + done)
     bytes_per_step = 2 * C + 9
-    avg_launch_s = kernel_ms * 1e-3 / launches
+    launches = launches_per_rep
+    avg_launch_s = med_ms * 1e-3 / launches
     steps_per_launch = args.steps / launches
     achieved = E * steps_per_launch * bytes_per_step / avg_launch_s / 1e9
 
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE is half-counted on gfx950, MI355X_MICROARCH.md HBM section); null if the
-    # profile was taken for another configuration
+    # profile was taken for another configuration or kernel
     traffic, on_chip = None, None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "bench_pmc_summary.json")))
         if (prof["config"] == {"board": N, "envs": E, "steps_per_launch": T}
-                and main_kernel.endswith("rollout1>")):
-            traffic = (2 * prof["FETCH_SIZE_KiB"] + prof["WRITE_SIZE_KiB"]) * 1024.0
+                and prof["kernel"].startswith(main_kernel.split("<")[0])):
             c = prof["counters"]["rollout1"]
+            traffic = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
             glob_insts = c["SQ_INSTS_VMEM_RD"] + c["SQ_INSTS_VMEM_WR"]
             on_chip = {"lds_insts_per_launch": c["SQ_INSTS_LDS"], "global_insts_per_launch": glob_insts,
-                       "lds_share_of_memory_insts": c["SQ_INSTS_LDS"] / (c["SQ_INSTS_LDS"] + glob_insts),
-                       "lds_bank_conflict_cycle_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
-                       "source": "profiles/r01/bench_pmc_summary.json (rocprofv3 --pmc, same command)"}
+                       "valu_insts_per_launch": c["SQ_INSTS_VALU"], "salu_insts_per_launch": c["SQ_INSTS_SALU"],
+                       "note": "the game state lives in registers (bitboards): no LDS traffic at all; "
+                               "global instructions are the observation / mask / scalar stores",
+                       "source": f"profiles/{PROFILE_ROUND}/bench_pmc_summary.json (rocprofv3 --pmc, same command)"}
     except Exception:
         traffic, on_chip = None, None
 
     extra = {}
     if not args.no_host_stepped:
-        ks = min(args.steps, 1000)
-        for _ in range(100):
-            env.step()
+        # one hexvec_step launch per env step on a default handle (bitboard state: 144 B per board at 11x11)
+        envs = hx.HexVecEnv(N, E, device=dev, encoding="B", seed=0, env_offset=rank * E)
+        ks = 1000
+        for _ in range(300):
+            envs.step()
         fence()
+        h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        h0.record()
         for _ in range(ks):
-            env.step()
+            envs.step()
+        h1.record()
         fence()
-        extra["host_stepped_env_steps_per_s"] = world * E * ks / (time.perf_counter() - t0)
-        extra["host_stepped_bytes_per_step"] = 3 * C + 9
+        hs_wall = time.perf_counter() - t0
+        extra["host_stepped"] = {"env_steps_per_s": world * E * ks / hs_wall,
+                                 "us_per_launch_stream": 1e3 * h0.elapsed_time(h1) / ks,
+                                 "bytes_per_step": 3 * C + 9, "kernel": envs.last_kernel(),
+                                 "achieved_GBps": E * ks * (3 * C + 9) / hs_wall / 1e9}
+        del envs
 
     # W2: two-sided device-resident rollout, every ply recorded (SURVEY 8(d) unit W2)
-    if not args.no_host_stepped:
+    if not args.no_w2:
         del out
-        env2 = hx.HexVecEnv(N, E, device=dev, encoding="B", two_sided=True, seed=1, env_offset=rank * E)
+        env2 = hx.HexVecEnv(N, E, device=dev, encoding="B", two_sided=True, seed=1, env_offset=rank * E,
+                            rollout_layout=args.layout == "rollout")
         T2 = 64
         out2 = dict(obs=torch.empty((T2, E, C), dtype=torch.int8, device=dev),
                     legal=torch.empty((T2, E, C), dtype=torch.uint8, device=dev),
@@ -196,7 +247,8 @@ def main():
             "metric": "env-steps/sec (random policy, 11x11)" if N == 11
                       else f"env-steps/sec (random policy, {N}x{N})",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "timed_reps": reps,
+            "warmup_internal_ms": warm_ms, "wall_ms_per_step": 1e3 * wall / (reps * args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{N}x{N} Hex, {E} envs/GPU, SelfPlayEnv.step with uniform-legal "
@@ -206,8 +258,10 @@ def main():
                        "steps_per_launch": T, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "obs_only_frac": achieved * C / bytes_per_step / HBM_PEAK_GBPS,
                          "kernel": main_kernel, "bytes_per_env_step": bytes_per_step,
-                         "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "avg_launch_ms": avg_launch_s * 1e3, "launches": launches * reps,
+                         "rep_ms_min_med_max": [rep_ms[0], med_ms, rep_ms[-1]],
                          "frac_of_copy_ceiling": achieved / HBM_COPY_GBPS},
             "episodes": {"sum_return": stats[0], "sum_len": stats[1], "n": stats[2],
                          "agent_wins": stats[3]},

@@ -20,6 +20,7 @@ F_NO_AUTO_RESET = 0x8
 F_FIRST_WHITE = 0x10
 F_TWO_SIDED = 0x20
 F_EXACT_LABELS = 0x40
+F_ROLLOUT_LAYOUT = 0x80
 
 MIN_BOARD, MAX_BOARD = 2, 14
 

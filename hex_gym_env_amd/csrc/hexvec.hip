@@ -1,7 +1,7 @@
 // hexvec.hip -- host side of libhexvec: the C ABI of include/hexvec.h.
 // Kernels: hexvec_wpb.hip (wave-per-board, literal engine), hexvec_qpb_{s,m,l}.hip (lanes-per-board
 // bitboards, the throughput path; hexvec_qpb.h), hexvec_lpb64.hip / hexvec_lpb32.hip (lane-per-board
-// union-find in LDS, the round-1 throughput path, kept selectable with HEXVEC_FAMILY=lpb for A/B runs).
+// union-find in LDS, the round-1 throughput path, the layout of HEXVEC_F_ROLLOUT_LAYOUT handles).
 #include <stdlib.h>
 
 #include "hexvec_common.h"
@@ -172,8 +172,9 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     // measured within 2 % of it on MI355X and stays selectable for experiments
     h->bpw = 64;
     if (const char *ev = getenv("HEXVEC_BPW")) h->bpw = atoi(ev) == 32 ? 32 : (atoi(ev) == 64 ? 64 : h->bpw);
-    h->qpb = true;
-    if (const char *ev = getenv("HEXVEC_FAMILY")) h->qpb = strcmp(ev, "lpb") != 0;
+    h->qpb = !(flags & HEXVEC_F_ROLLOUT_LAYOUT);
+    if (const char *ev = getenv("HEXVEC_FAMILY")) // A/B experiments
+        h->qpb = strcmp(ev, "lpb") == 0 ? false : (strcmp(ev, "qpb") == 0 ? true : h->qpb);
     if (h->fast_mode && h->qpb) {
         const int bpw = 64 / hv::qpb_lanes(board_size);
         const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 16;

@@ -355,6 +355,9 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
     const int gbase = lane & ~(L - 1); // first lane of the group
+    // Lanes past the last env leave now: a group is all live or all dead, nothing below is shared
+    // between groups (DPP carries between groups are zero by construction, ballots only ask "any").
+    if (!live) return;
 
     LS s;
     s.key = mix32(((u32)env + a.env_offset) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi;
@@ -366,7 +369,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                   : (a.flags & HEXVEC_F_AGENT_WHITE) ? 1 : 0;
         s.pend = 0;
         QQ::fresh_regs(s, first);
-        if (live && c.l == 0) *reinterpret_cast<int4 *>(stats) = make_int4(0, 0, 0, 0);
+        if (c.l == 0) *reinterpret_cast<int4 *>(stats) = make_int4(0, 0, 0, 0);
     } else {
         s.K0 = rblk[0 * 64 + lane];
         s.K1 = rblk[1 * 64 + lane];
@@ -469,15 +472,15 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             QQ::fresh_regs(s, first);
         }
     };
-    auto do_emit = [&](signed char *o, unsigned char *lg) { QQ::emit(s, live, o, lg, brow, c); };
-    const bool wr = live && c.l == 0; // the lane that writes the board's scalar outputs
+    auto do_emit = [&](signed char *o, unsigned char *lg) { QQ::emit(s, true, o, lg, brow, c); };
+    const bool wr = c.l == 0; // the lane that writes the board's scalar outputs
 
     const size_t E = (size_t)a.E;
 
     if (MODE == M_SETBOARD) {
         // HexEnv.reset with a given start position (sample_board, HexSingleGame.py:217-222): the
         // stones are replayed row-major like the constructor does (:57-65); nobody has moved yet.
-        const bool sel = live && (!a.env_mask || a.env_mask[env] != 0);
+        const bool sel = !a.env_mask || a.env_mask[env] != 0;
         if (sel) {
             s.pend = 0;
             QQ::fresh_regs(s, first);
@@ -495,7 +498,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
         if (wr && a.pending) a.pending[env] = (unsigned char)s.pend;
         do_emit(a.obs ? a.obs + (size_t)e0 * C : nullptr, a.legal ? a.legal + (size_t)e0 * C : nullptr);
     } else if (MODE == M_RESET) {
-        const bool sel = live && (a.init || !a.env_mask || a.env_mask[env] != 0);
+        const bool sel = a.init || !a.env_mask || a.env_mask[env] != 0;
         if (sel) {
             s.pend = 0;
             QQ::fresh_regs(s, first);
@@ -513,7 +516,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             int rew = 0, won = 0;
             bool fin = false; // the env step completed in this call
             if (a.phase == 1) { // the agent's ply (slot 1)
-                if (live && s.pend == 0) {
+                if (s.pend == 0) {
                     const int act = ext_a ? a.actions[o] : QQ::rng_action(s, B ? s.cur : 0, c);
                     if (B) {
                         const int rb = envb_step(act, ext_a);
@@ -528,7 +531,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                 }
             } else { // the opponent's plies: replies (slot 2) and openings (slot 3)
                 const int was = s.pend;
-                if (live && was != 0) {
+                if (was != 0) {
                     const int oa = ext_o ? a.opp_actions[o] : QQ::rng_action(s, B ? s.cur : 1, c);
                     const int rb = opponent_ply(oa, ext_o);
                     s.pend = 0;
@@ -563,7 +566,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             // ---- slot 1: the agent's ply (two-sided: the mover's)
             int rew = 0, won = 0, f_done = 0, f_winner = -1, act = 0;
             bool reply = false; // this board still owes the opponent's reply
-            if (live) {
+            {
                 act = ext_a ? a.actions[o] : QQ::rng_action(s, B ? s.cur : 0, c); // B: the mover's frame
                 if (two) {
                     const int mover = s.cur;
@@ -600,7 +603,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                     f_winner = s.winner;
                 }
             }
-            const bool dn1 = live && !reply && s.done;
+            const bool dn1 = !reply && s.done;
             handle_done(dn1, won, tobs_row);
             // ---- slot 2: the opponent's reply, or its opening on the boards just reset
             if (selfplay) {
@@ -648,7 +651,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
 #pragma unroll
     for (int k = 0; k < G::NSC; ++k)
         if (c.l == k % L) rblk[(8 + k / L) * 64 + lane] = k == 0 ? s.ctr : (k == 1 ? fl : ep);
-    if (live && c.l == 0 && s.se != 0) { // episode sums: touched only when an episode ended in this launch
+    if (c.l == 0 && s.se != 0) { // episode sums: touched only when an episode ended in this launch
         int4 v = *reinterpret_cast<int4 *>(stats);
         v.x += s.sr;
         v.y += s.sl;

@@ -1,4 +1,4 @@
-"""HexVecEnv: tensor-native front end of libhexvec (one wavefront per board).
+"""HexVecEnv: tensor-native front end of libhexvec.
 
 All observations / masks / rewards / dones are torch tensors on the GPU; the
 calls enqueue on torch's current stream and never synchronise.  The semantics
@@ -27,7 +27,7 @@ def _p(t):
 class HexVecEnv:
     def __init__(self, board_size=11, num_envs=1024, device=None, seed=0, encoding="B",
                  two_sided=False, agent_player_num=None, auto_reset=True, first_player=0,
-                 env_offset=0, exact_labels=False):
+                 env_offset=0, exact_labels=False, rollout_layout=False):
         if not (_lib.MIN_BOARD <= board_size <= _lib.MAX_BOARD):
             raise ValueError(f"board_size must be in {_lib.MIN_BOARD}..{_lib.MAX_BOARD}")
         if encoding not in ("A", "B"):
@@ -62,7 +62,9 @@ class HexVecEnv:
             flags |= _lib.F_NO_AUTO_RESET
         if exact_labels:
             flags |= _lib.F_EXACT_LABELS
-        # auto-reset handles run on the lane-per-board kernels (include/hexvec.h)
+        if rollout_layout:      # state laid out for rollout_selfplay / rollout_random (include/hexvec.h)
+            flags |= _lib.F_ROLLOUT_LAYOUT
+        # auto-reset handles run on the bitboard / lane-per-board kernels (include/hexvec.h)
         self.exact = (not auto_reset) or exact_labels or board_size < 4
         self.board_size, self.num_envs, self.encoding = board_size, num_envs, encoding
         self.two_sided, self.auto_reset, self.flags = two_sided, auto_reset, flags

@@ -25,12 +25,18 @@
  *   - board_size 2..14 (connectivity entries / labels are one byte; a padded label
  *     plane is one dword per lane); larger boards are rejected with HEXVEC_E_ARG.
  *
- * Two kernel families serve a handle, chosen at create time:
- *   - auto-reset handles (the default) run on the lane-per-board kernels: one
- *     lane owns one board, connectivity by union-find.  winner / done / reward /
- *     obs / legal mask are bit-exact; the reference's internal label planes are
- *     not kept (hexvec_get_state(labels != NULL) and hexvec_apply_moves return
- *     HEXVEC_E_MODE).
+ * Three kernel families serve a handle, chosen at create time:
+ *   - auto-reset handles (the default) run on the bitboard kernels: 1 / 2 / 4 / 8
+ *     lanes own one board (4 at 9x9..11x11), the whole game state is 8 bitboards in
+ *     registers (144 B per board in HBM between calls), connectivity by edge-connected
+ *     sets grown with a frontier flood.  This is the layout for host-stepped use
+ *     (hexvec_step and the split step move the least state) and for any board count.
+ *   - auto-reset handles created with HEXVEC_F_ROLLOUT_LAYOUT run on the lane-per-board
+ *     kernels: one lane owns one board, connectivity by union-find in LDS (2.3x fewer
+ *     vector instructions per ply, 4x the state): the layout for hexvec_rollout_*.
+ *     On both, winner / done / reward / obs / legal mask are bit-exact; the reference's
+ *     internal label planes are not kept (hexvec_get_state(labels != NULL) and
+ *     hexvec_apply_moves return HEXVEC_E_MODE).
  *   - HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS handles run on the
  *     wave-per-board kernels, a literal restatement that also reproduces
  *     `regions`, illegal plies without state change and plies after the end.
@@ -71,6 +77,10 @@ typedef struct hexvec hexvec_t;
 #define HEXVEC_F_FIRST_WHITE 0x10u  /* enc A: constructor current_player_num = WHITE (HexGame.py:155) */
 #define HEXVEC_F_TWO_SIDED 0x20u    /* no in-env opponent: step = one ply of whoever is to move  */
 #define HEXVEC_F_EXACT_LABELS 0x40u /* keep the reference's label planes (regions) bit for bit; see below */
+#define HEXVEC_F_ROLLOUT_LAYOUT 0x80u /* auto-reset handles: keep the state in the layout the device-resident
+                                        rollouts run fastest on (one lane per board, union-find in LDS) instead
+                                        of the default bitboards; every entry point works on either layout with
+                                        identical results, only the speed differs (see below)                    */
 
 /* Allocates the internal state for num_envs boards on device_id and resets
  * them (replaces HexEnv.__init__ HexGame.py:152-197 / HexSingleGame.py:163-196,

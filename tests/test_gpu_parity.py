@@ -163,16 +163,20 @@ def _flags(enc, two_sided, agent, auto_reset, first):
     return f
 
 
-FAMILIES = pytest.mark.parametrize("exact", [False, True], ids=["lane-per-board", "wave-per-board"])
+# exact: False = bitboard kernels (default), "lpb" = lane-per-board union-find (rollout layout),
+# True = wave-per-board literal engine
+FAMILIES = pytest.mark.parametrize("exact", [False, "lpb", True],
+                                   ids=["bitboard", "lane-per-board", "wave-per-board"])
 
 
 def _pair(hx, n, E, enc, two_sided=False, agent=None, auto_reset=True, first=0, seed=7, off=0,
           exact=False):
+    lpb, exact = exact == "lpb", exact is True
     g = hx.HexVecEnv(n, E, encoding=enc, two_sided=two_sided, agent_player_num=agent,
                      auto_reset=auto_reset, first_player=first, seed=seed, env_offset=off,
-                     exact_labels=exact)
+                     exact_labels=exact, rollout_layout=lpb)
     assert g.exact == (exact or not auto_reset or n < 4)
-    assert g.last_kernel().startswith("k_hex" if g.exact else ("k_qpb", "k_lpb"))
+    assert g.last_kernel().startswith("k_hex" if g.exact else ("k_lpb" if lpb else "k_qpb"))
     o = ho.OracleVec(n, E, seed=seed, flags=_flags(enc, two_sided, agent, auto_reset, first),
                      env_offset=off)
     return g, o
@@ -379,19 +383,23 @@ def test_errors_are_loud(hx):
         e.step(np.zeros(3, np.int32))
 
 
-@pytest.mark.parametrize("n,E", [(5, 70), (11, 65), (7, 1), (4, 129)])
+LAYOUTS = pytest.mark.parametrize("lay", [False, "lpb"], ids=["bitboard", "lane-per-board"])
+
+
+@pytest.mark.parametrize("n,E", [(5, 70), (11, 65), (7, 1), (4, 129), (13, 9), (8, 33)])
 @pytest.mark.parametrize("enc", ["A", "B"])
-def test_lane_per_board_odd_env_counts(hx, n, E, enc):
-    """partial last block of 64 boards and unaligned output rows (byte-store path)"""
+@LAYOUTS
+def test_lane_per_board_odd_env_counts(hx, n, E, enc, lay):
+    """partial last wavefront and unaligned output rows"""
     T = 3 * n
-    g, o = _pair(hx, n, E, enc, two_sided=True, seed=77)
+    g, o = _pair(hx, n, E, enc, two_sided=True, seed=77, exact=lay)
     out = g.rollout_random(T)
     oobs, olegal, oact, orew, odone = o.rollout(T)
     assert np.array_equal(_np(out["obs"]), oobs)
     assert np.array_equal(_np(out["legal"]), olegal)
     assert np.array_equal(_np(out["actions"]), oact)
     assert np.array_equal(_np(out["done"]), odone)
-    g2, o2 = _pair(hx, n, E, enc, agent=None, seed=78)
+    g2, o2 = _pair(hx, n, E, enc, agent=None, seed=78, exact=lay)
     for k in range(2 * n):
         obs, rew, done, legal, win = g2.step()
         oo, ol, orw, od, ow = o2.step()
@@ -403,13 +411,14 @@ def test_lane_per_board_odd_env_counts(hx, n, E, enc):
 
 
 @pytest.mark.parametrize("n", list(range(4, 15)))
-def test_soak_all_sizes_lane_per_board_vs_oracle(hx, n):
+@LAYOUTS
+def test_soak_all_sizes_lane_per_board_vs_oracle(hx, n, lay):
     """long differential run per board size: hundreds of episodes per env, both encodings, RNG and
     external (partly illegal) actions mixed, masked resets in between"""
     E, K = 256, 300
     rng = np.random.default_rng(1000 + n)
     for enc, agent, first in (("B", None, 0), ("A", None, n % 2)):
-        g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=4242 + n)
+        g, o = _pair(hx, n, E, enc, agent=agent, first=first, seed=4242 + n, exact=lay)
         for k in range(K):
             if k % 5 == 4:
                 a = rng.integers(0, n * n, size=E).astype(np.int32)
@@ -419,9 +428,8 @@ def test_soak_all_sizes_lane_per_board_vs_oracle(hx, n):
             oo, ol, orw, od, ow = o.step(a)
             assert np.array_equal(_np(rew), orw) and np.array_equal(_np(done), od), (enc, k)
             assert np.array_equal(_np(win), ow), (enc, k)
-            if k % 7 == 0 or k == K - 1:
-                assert np.array_equal(_np(obs).reshape(E, -1), oo), (enc, k)
-                assert np.array_equal(_np(legal), ol), (enc, k)
+            assert np.array_equal(_np(obs).reshape(E, -1), oo), (enc, k)
+            assert np.array_equal(_np(legal), ol), (enc, k)
             if k % 97 == 50:
                 m = (rng.random(E) < 0.2).astype(np.uint8)
                 gobs, glegal = g.reset(env_mask=m)
@@ -432,10 +440,11 @@ def test_soak_all_sizes_lane_per_board_vs_oracle(hx, n):
         _same_state(g, o)
 
 
-def test_soak_two_sided_rollout_long(hx):
+@LAYOUTS
+def test_soak_two_sided_rollout_long(hx, lay):
     """W2 over many launches: state carried across launches, ~10^2 episodes per env"""
     n, E = 9, 512
-    g, o = _pair(hx, n, E, "B", two_sided=True, seed=606)
+    g, o = _pair(hx, n, E, "B", two_sided=True, seed=606, exact=lay)
     for launch in range(12):
         T = 37 + launch
         out = g.rollout_random(T, out={k: torch.empty((T, E) + ((n * n,) if k in ("obs", "legal") else ()),
