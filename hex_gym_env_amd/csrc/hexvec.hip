@@ -421,9 +421,9 @@ extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)
     HV_HANDLE(h);
     if (!out4) return fail(HEXVEC_E_ARG, "%s", "out4 is NULL");
     HV_DEVICE(h);
+    HV_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(double), (hipStream_t)stream)); // the blocks add their partial sums
     if (h->fast_mode && h->qpb) {
         g_kernel = "k_qpb_stats";
-        HV_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(double), (hipStream_t)stream));
         HV_HIP(HV_QPB_CALL(h->N, stats, h->fast, h->N, h->E, out4, nullptr, (hipStream_t)stream));
         return HEXVEC_OK;
     }

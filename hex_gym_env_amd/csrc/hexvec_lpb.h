@@ -813,12 +813,13 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
     using L = Lpb<N, ENC, BPW>;
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < E; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
         const unsigned char *sblk = fast + (size_t)(i / BPW) * FastState<N, ENC, BPW>::BLOCK_BYTES;
         const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
         for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i % BPW)];
         if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i % BPW)] >> 3) & 1u);
     }
+    if (!out4) return;
     for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
@@ -826,7 +827,8 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
             for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
         __syncthreads();
     }
-    if (out4 && threadIdx.x < 4) out4[threadIdx.x] = sh[threadIdx.x][0];
+    // out4 was zeroed on the same stream; sums of integers are exact in any order
+    if (threadIdx.x < 4) atomicAdd(&out4[threadIdx.x], sh[threadIdx.x][0]);
 }
 
 } // namespace lpb
@@ -893,11 +895,12 @@ hipError_t HV_LPB_NAME(get_state)(const unsigned char *fast, int N, int enc, int
 hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int E, double *out4,
                               unsigned char *agents, hipStream_t st)
 {
+    const dim3 grid((E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024);
     switch (N) {
 #define HV_CASE(n)                                                                                                  \
     case n:                                                                                                         \
-        if (enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW>), dim3(1), dim3(256), 0, st, fast, E, out4, agents); \
-        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0, HV_BPW>), dim3(1), dim3(256), 0, st, fast, E, out4, agents);     \
+        if (enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW>), grid, dim3(256), 0, st, fast, E, out4, agents); \
+        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0, HV_BPW>), grid, dim3(256), 0, st, fast, E, out4, agents);     \
         break;
         HV_LPB_SIZES(HV_CASE)
 #undef HV_CASE

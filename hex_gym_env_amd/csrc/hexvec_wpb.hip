@@ -548,7 +548,7 @@ __global__ void k_stats(const int *stats, int E, double *out4)
 {
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < E; i += blockDim.x)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x)
         for (int k = 0; k < 4; ++k) acc[k] += (double)stats[(size_t)i * STAT_WORDS + k];
     for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = acc[k];
     __syncthreads();
@@ -557,7 +557,7 @@ __global__ void k_stats(const int *stats, int E, double *out4)
             for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x < 4) out4[threadIdx.x] = sh[threadIdx.x][0];
+    if (threadIdx.x < 4) atomicAdd(&out4[threadIdx.x], sh[threadIdx.x][0]); // sums of integers: exact in any order
 }
 
 __global__ void k_agents(const u32 *hot, int E, unsigned char *out)
@@ -612,7 +612,9 @@ hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int en
 }
 hipError_t wpb_stats(const int *stats, int E, double *out4, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(256), 0, st, stats, E, out4);
+    // out4 was zeroed on the same stream (hexvec_episode_stats)
+    const int grid = (E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024;
+    hipLaunchKernelGGL(k_stats, dim3(grid), dim3(256), 0, st, stats, E, out4);
     return hipGetLastError();
 }
 hipError_t wpb_agents(const u32 *hot, int E, unsigned char *out, hipStream_t st)

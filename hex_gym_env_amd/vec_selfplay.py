@@ -58,31 +58,55 @@ def sample_boards(board_size, count, generator, device):
     return board.view(count, n, n)
 
 
-def sample_masked(logits, legal, generator=None):
+def sample_masked(logits, legal, generator=None, bad_rows=None):
     """One categorical sample per row from softmax(logits) restricted to legal != 0, by the Gumbel-max
     trick: argmax(logits + G).  Same distribution as multinomial(softmax(masked logits)) but without
-    torch.multinomial's device-side assertion, so it can be captured in a hipGraph and a degenerate
-    row (no legal cell) yields action 0 instead of trapping the GPU."""
+    torch.multinomial's device-side assertion, so it can be captured in a hipGraph.
+
+    A DEGENERATE row -- no legal cell, or a non-finite logit on a legal cell -- cannot be sampled; it
+    yields action 0 (an illegal ply, which ends the episode with reward 0) and is COUNTED in `bad_rows`
+    (int64 scalar on the device, incremented in place) so that it never passes silently: the policies
+    below own such a counter and VecSelfPlayEnv.degenerate_rows() reads them."""
+    ok = legal != 0
+    lf = logits.float()
+    if bad_rows is not None:
+        bad = ~ok.any(1) | (ok & ~torch.isfinite(lf)).any(1)
+        bad_rows.add_(bad.sum())
     u = torch.rand(logits.shape, generator=generator, device=logits.device, dtype=torch.float32)
     g = -torch.log(-torch.log(u.clamp_(1e-20, 1.0 - 1e-7)))
-    z = torch.where(legal != 0, logits.float() + g, torch.full_like(g, float("-inf")))
+    z = torch.where(ok, lf + g, torch.full_like(g, float("-inf")))
     return z.argmax(1)
 
 
-class RandomLegalPolicy:
+class _CountsBadRows:
+    """per-policy device counter of degenerate sampling rows (see sample_masked)"""
+    _bad_rows = None
+
+    def bad_rows_counter(self, device):
+        if self._bad_rows is None or self._bad_rows.device != torch.device(device):
+            self._bad_rows = torch.zeros((), dtype=torch.long, device=device)
+        return self._bad_rows
+
+
+class RandomLegalPolicy(_CountsBadRows):
     """uniform over the empty cells, drawn with torch's generator on the device"""
 
     def __init__(self, generator=None):
         self.generator = generator
 
+    def group_key(self):
+        """policies with equal keys answer identically distributed and may share one batched call"""
+        return ("random-legal", id(self.generator))
+
     def choose_actions(self, obs, legal):
-        return sample_masked(torch.zeros(legal.shape, device=legal.device), legal, self.generator)
+        return sample_masked(torch.zeros(legal.shape, device=legal.device), legal, self.generator,
+                             self.bad_rows_counter(legal.device))
 
     def save_model(self, path):
         return None
 
 
-class MlpActorPolicy(torch.nn.Module):
+class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
     """The actor of sb3_contrib's MaskableActorCriticPolicy with the default MLP extractor:
     flatten -> float -> Linear-Tanh-Linear-Tanh (mlp_extractor.policy_net) -> Linear (action_net)
     -> logits, illegal actions masked out, categorical sample (or argmax)."""
@@ -135,7 +159,8 @@ class MlpActorPolicy(torch.nn.Module):
         if self.deterministic:
             return self.logits(obs, legal).argmax(1)
         x = obs.reshape(obs.shape[0], -1).float()
-        return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator)
+        return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator,
+                             self.bad_rows_counter(legal.device))
 
     def save_model(self, path):
         torch.save(self.state_dict(), path)
@@ -227,13 +252,20 @@ class VecSelfPlayEnv:
             new = self._cand
         self.slot.copy_(torch.where(mask, new, self.slot))         # in place: hipGraph replays read this tensor
 
-    def _opponent_actions(self, obs, legal, pending):
-        """actions of every pending board's opponent.  Boards are grouped by distinct policy OBJECT
-        (the reference's pool mostly holds the same live model); each distinct policy is evaluated
-        on the whole batch and its answers are kept where that policy is the opponent."""
+    def _groups(self):
+        """slots grouped by policy: the same OBJECT (the reference's pool mostly holds the same live
+        model) or an equal group_key() (stateless policies such as the default random pool)"""
         groups = {}
         for k in range(-1, len(self.buffer)):
-            groups.setdefault(id(self.buffer.policy(k)), (self.buffer.policy(k), []))[1].append(k)
+            pol = self.buffer.policy(k)
+            key = pol.group_key() if hasattr(pol, "group_key") else id(pol)
+            groups.setdefault(key, (pol, []))[1].append(k)
+        return groups
+
+    def _opponent_actions(self, obs, legal, pending):
+        """actions of every pending board's opponent: each distinct policy group is evaluated on the
+        whole batch and its answers are kept where that policy is the opponent."""
+        groups = self._groups()
         safe_legal = torch.where(pending.view(-1, 1).bool(), legal, torch.ones_like(legal))
         first = True
         for pol, slots in groups.values():
@@ -251,14 +283,14 @@ class VecSelfPlayEnv:
         """openings on EMPTY boards: every board that shares a policy has the same distribution, so a
         policy exposing logits() is evaluated on one empty board and sampled once per board"""
         n, E = self.board_size, self.num_envs
-        groups = {}
-        for k in range(-1, len(self.buffer)):
-            groups.setdefault(id(self.buffer.policy(k)), (self.buffer.policy(k), []))[1].append(k)
+        groups = self._groups()
         full = self._all_legal
         for pol, slots in groups.values():
             if hasattr(pol, "logits"):
                 z = pol.logits(self._empty_board[:1], full[:1])
-                a = sample_masked(z.expand(E, -1), full, getattr(pol, "generator", None)).to(torch.int32)
+                a = sample_masked(z.expand(E, -1), full, getattr(pol, "generator", None),
+                                  pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter")
+                                  else None).to(torch.int32)
             else:
                 a = pol.choose_actions(self._empty_board, full).to(torch.int32)
             if len(groups) == 1:
@@ -332,39 +364,73 @@ class VecSelfPlayEnv:
         self._setup_opponents((self.vec.done != 0) & ~ended1 & ~self._white)
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
+    def _pool_version(self):
+        """everything host-side that a captured collection step bakes in: the pool's policy objects and
+        their grouping, the evaluation flag, the 80/20 split"""
+        return (tuple(id(self.buffer.policy(k)) for k in range(-1, len(self.buffer))),
+                bool(self.buffer.evaluating), float(self.buffer.prob_best), self._any_white)
+
     def capture_collect_step(self, agent_policy, warmup=3):
         """Capture  actions = agent_policy.choose_actions(obs, legal); step(actions)  as ONE hipGraph
         (torch.cuda.CUDAGraph).  step() never synchronises and all shapes are static, so the ~40 small
         launches of a collection step replay with a single host call.  Returns run() -> (obs, reward,
         done, legal, winner, actions); the tensors are static buffers overwritten by every run().
-        The policies must be capturable (no host synchronisation, default or registered generators)."""
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        holder = {}
+        The policies must be capturable (no host synchronisation, default or registered generators).
+
+        The graph bakes in host-side state: WHICH policy objects are in the pool (and how slots group),
+        the evaluation flag and the 80/20 split.  set_eval() / set_opponent_model() / any change of
+        `buffer` therefore invalidate it: run() notices (the pool is fingerprinted at capture) and
+        captures again before replaying, so the reference's SelfPlayCallback cycle (set_eval ->
+        evaluate -> set_opponent_model, SelfplayWrapper.py:113-136) always plays the current opponents;
+        `run.captures` counts the captures."""
+        holder = {"captures": 0}
 
         def body():
             a = agent_policy.choose_actions(self.vec.obs, self.vec.legal)
             holder["actions"] = a
             self.step(a)
 
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                body()
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            if hasattr(graph, "register_generator_state"):
-                graph.register_generator_state(self._gen)
-            with torch.cuda.graph(graph, stream=side):
-                body()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        self._graph = graph
+        def capture():
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    body()
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                if hasattr(graph, "register_generator_state"):
+                    graph.register_generator_state(self._gen)
+                with torch.cuda.graph(graph, stream=side):
+                    body()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            holder["graph"], holder["version"] = graph, self._pool_version()
+            holder["captures"] += 1
+            self._graph = graph
+
+        capture()
 
         def run():
-            graph.replay()
+            if holder["version"] != self._pool_version():
+                capture()
+            run.captures = holder["captures"]
+            holder["graph"].replay()
             return (self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner,
                     holder["actions"])
 
+        run.captures = 1
         return run
+
+    def degenerate_rows(self, *more_policies):
+        """number of sampling rows so far that had no legal cell or a non-finite logit (sample_masked),
+        over the pool's policies (+ any given, e.g. the agent's); one host read.  Always 0 in a healthy
+        run: boards handed to a policy always have an empty cell."""
+        seen, tot = set(), 0
+        for pol in [self.buffer.policy(k) for k in range(-1, len(self.buffer))] + list(more_policies):
+            c = getattr(pol, "_bad_rows", None)
+            if c is not None and id(c) not in seen:
+                seen.add(id(c))
+                tot += int(c)
+        return tot
 
     def legal_actions(self):
         return self.vec.legal

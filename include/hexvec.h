@@ -106,6 +106,9 @@ int hexvec_reset(hexvec_t *h, const uint8_t *env_mask, const int32_t *opp_action
  * TWO_SIDED handles: HexEnv.step HexSingleGame.py:233-263 (enc B) / one
  *   HexGame.make_move HexGame.py:85-111 (enc A): one ply, reward of the mover.
  * actions NULL = uniform-legal RNG agent; opp_actions NULL = RNG opponent.
+ * opp_actions, when given, supply the opponent's REPLIES only: the opening of a board that is
+ * reset inside this call (the opponent moves first on it) is always drawn by the library RNG --
+ * a caller who wants to choose openings too uses the split step below.
  * terminal_obs (int8 [E, N*N], optional) receives the final board of envs that
  * finished in this call (untouched otherwise). */
 int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *opp_actions, int8_t *obs,
@@ -125,7 +128,9 @@ int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *opp_actions,
  *   hexvec_step_opponent(opp_actions)     ... repeated until no board is pending.
  * reward / done / winner / terminal_obs are written only for the boards whose step completes
  * in that call, obs / legal / pending (uint8 [E]) for all boards.  actions / opp_actions may be
- * NULL (uniform-legal RNG).  The result equals hexvec_step with the same actions. */
+ * NULL (uniform-legal RNG).  With opp_actions == NULL throughout, the result (and the RNG stream) equals
+ * hexvec_step with the same agent actions; with caller-supplied opp_actions the split step also takes the
+ * OPENINGS from the caller (pending == 2 boards) and draws nothing, where hexvec_step draws them itself. */
 int hexvec_step_agent(hexvec_t *h, const int32_t *actions, int8_t *obs, uint8_t *legal, float *reward,
                       uint8_t *done, int8_t *winner, int8_t *terminal_obs, uint8_t *pending,
                       void *stream);

@@ -143,6 +143,85 @@ def test_hexv0_step_matches_reference_fixtures(hx):
             env.close()
 
 
+def _replay_episodes_auto_reset(hx, d, n, eps, enc, lay, **kw):
+    """Fixture episodes through an AUTO-RESET handle (the throughput kernels): every ply of every
+    episode up to its own end is compared (obs, mask, reward, done, winner); the final ply's
+    observation is the terminal_obs row, because the returned obs already shows the next episode."""
+    E = len(eps)
+    env = hx.HexVecEnv(n, E, encoding=enc, rollout_layout=lay == "lpb", **kw)
+    ro = np.array([max(int(d[f"N{n}_e{e}_reset_opp_action"]), 0) for e in eps], np.int32)
+    obs, legal = env.reset(opp_actions=ro)
+    if n >= 4:
+        assert env.last_kernel().startswith("k_lpb" if lay == "lpb" else "k_qpb")
+    obs, legal = _np(obs).reshape(E, -1), _np(legal)
+    for i, e in enumerate(eps):
+        k = f"N{n}_e{e}_"
+        assert np.array_equal(obs[i], d[k + "reset_obs"]), k
+        assert np.array_equal(legal[i], _unpack(d[k + "reset_mask"], n)), k
+    T = max(len(d[f"N{n}_e{e}_actions"]) for e in eps)
+    over = np.zeros(E, bool)
+    tobs = torch.full((E, n, n), 99, dtype=torch.int8, device="cuda")
+    empty = 0 if enc == "B" else 2
+    checked = 0
+    for t in range(T):
+        a = np.zeros(E, np.int32)
+        oa = np.zeros(E, np.int32)
+        for i, e in enumerate(eps):
+            k = f"N{n}_e{e}_"
+            if t < len(d[k + "actions"]):
+                a[i] = d[k + "actions"][t]
+                oa[i] = max(int(d[k + "opp_actions"][t]), 0)
+        obs, rew, done, legal, win = env.step(a, oa, terminal_obs=tobs)
+        obs, rew, done, legal, win = _np(obs).reshape(E, -1), _np(rew), _np(done), _np(legal), _np(win)
+        tb = _np(tobs).reshape(E, -1)
+        for i, e in enumerate(eps):
+            k = f"N{n}_e{e}_"
+            if over[i] or t >= len(d[k + "actions"]):
+                continue
+            assert rew[i] == d[k + "reward"][t], (k, t)
+            assert done[i] == d[k + "done"][t], (k, t)
+            if k + "winner" in d:
+                assert win[i] == d[k + "winner"][t], (k, t)
+            m = _unpack(d[k + "mask"], n)[t]
+            if done[i]:
+                assert np.array_equal(tb[i], d[k + "obs"][t]), (k, t, "terminal obs")
+                assert np.array_equal((tb[i] == empty).astype(np.uint8), m), (k, t)
+                over[i] = True
+            else:
+                assert np.array_equal(obs[i], d[k + "obs"][t]), (k, t)
+                assert np.array_equal(legal[i], m), (k, t)
+            checked += 1
+    env.close()
+    return checked
+
+
+LAYOUTS = pytest.mark.parametrize("lay", [False, "lpb"], ids=["bitboard", "lane-per-board"])
+
+
+@LAYOUTS
+def test_selfplay_fixtures_on_auto_reset_handles(hx, lay):
+    """SelfPlayEnv episodes of the reference (SelfplayWrapper.py:174-199) on the throughput kernels"""
+    d = np.load(os.path.join(GOLDEN, "selfplay.npz"))
+    tot = 0
+    for n in (int(x) for x in d["sizes"]):
+        for agent in (0, 1):
+            eps = [e for e in range(int(d[f"N{n}_neps"])) if int(d[f"N{n}_e{e}_agent"]) == agent]
+            tot += _replay_episodes_auto_reset(hx, d, n, eps, "B", lay, agent_player_num=agent)
+    assert tot > 200
+
+
+@LAYOUTS
+def test_hexv0_fixtures_on_auto_reset_handles(hx, lay):
+    """hex-v0 HexEnv episodes of the reference (HexGame.py:244-295) on the throughput kernels"""
+    d = np.load(os.path.join(GOLDEN, "envA.npz"))
+    tot = 0
+    for n in (int(x) for x in d["sizes"]):
+        for first in (0, 1):
+            eps = [e for e in range(int(d[f"N{n}_neps"])) if int(d[f"N{n}_e{e}_first"]) == first]
+            tot += _replay_episodes_auto_reset(hx, d, n, eps, "A", lay, first_player=first)
+    assert tot > 100
+
+
 # ----------------------------------------------------------------------------
 # oracle on seeded inputs
 # ----------------------------------------------------------------------------
@@ -383,9 +462,6 @@ def test_errors_are_loud(hx):
         e.step(np.zeros(3, np.int32))
 
 
-LAYOUTS = pytest.mark.parametrize("lay", [False, "lpb"], ids=["bitboard", "lane-per-board"])
-
-
 @pytest.mark.parametrize("n,E", [(5, 70), (11, 65), (7, 1), (4, 129), (13, 9), (8, 33)])
 @pytest.mark.parametrize("enc", ["A", "B"])
 @LAYOUTS
@@ -496,8 +572,61 @@ def test_config1_thousand_reference_games_5x5(hx):
     assert np.array_equal(ret[played], rets.T[played])
     last = played.sum(0) - 1
     assert (done[last, np.arange(G)] == 1).all() and (done[0] == 0).all()
-    # and through the single-ply step of the lane-per-board kernels (auto reset on the winning ply)
-    fast = hx.HexVecEnv(n, G, encoding="A", two_sided=True)
-    for t in range(int(last.min()) + 1):
-        o, r, dn, lg, w = fast.step(acts[:, t])
-        assert np.array_equal(_np(w), rets[:, t]), t
+    # and through the single-ply step of both throughput layouts (auto reset on the winning ply): every
+    # ply of every game to that game's own end -- winner code, done, observation (the terminal one for
+    # the last ply), legal mask -- against the literal engine's rows, which the fixture pins
+    for lay in (False, True):
+        fast = hx.HexVecEnv(n, G, encoding="A", two_sided=True, rollout_layout=lay)
+        tobs = torch.full((G, n, n), 99, dtype=torch.int8, device="cuda")
+        alive = np.ones(G, bool)
+        for t in range(T):
+            a = np.where(acts[:, t] >= 0, acts[:, t], 0).astype(np.int32)
+            o, r, dn, lg, w = fast.step(a, terminal_obs=tobs)
+            assert fast.last_kernel().startswith("k_lpb" if lay else "k_qpb")
+            o, dn, lg, w, tb = _np(o).reshape(G, -1), _np(dn), _np(lg), _np(w), _np(tobs).reshape(G, -1)
+            cur = alive & (acts[:, t] >= 0)
+            assert np.array_equal(w[cur], rets[cur, t]), t
+            assert np.array_equal(dn[cur], done[t, cur]), t
+            fin = cur & (dn == 1)
+            go = cur & (dn == 0)
+            assert np.array_equal(o[go], obs[t, go]) and np.array_equal(lg[go], legal[t, go]), t
+            assert np.array_equal(tb[fin], obs[t, fin]), t
+            alive &= ~fin
+        assert not alive.any()
+
+
+@LAYOUTS
+@pytest.mark.parametrize("two", [False, True], ids=["selfplay", "two-sided"])
+def test_config4_all_524288_envs_on_one_gpu_and_shard_identity(hx, lay, two):
+    """BASELINE config 4 (11x11, 524 288 envs = 8 x 65 536): the whole job on ONE GPU -- size-independent
+    properties on every row -- and sharding: rank 7's shard (env_offset = 7E/8) reproduces the last eighth of
+    the monolithic run bit for bit, and its first envs match the oracle started at the same global ids."""
+    n, E, T = 11, 524288, 8
+    kw = dict(encoding="B", two_sided=two, seed=2, rollout_layout=lay == "lpb")
+    env = hx.HexVecEnv(n, E, **kw)
+    fn = env.rollout_random if two else env.rollout_selfplay
+    o1 = fn(T)
+    assert env.last_kernel().startswith("k_lpb" if lay == "lpb" else "k_qpb")
+    obs, legal, done, act = o1["obs"], o1["legal"], o1["done"], o1["actions"]
+    assert torch.equal(legal, (obs == 0).to(torch.uint8))
+    assert int(((act < 0) | (act >= n * n)).sum()) == 0
+    if two:     # the recorded action was legal in the recorded position
+        assert bool(torch.gather(legal, 2, act.long().unsqueeze(-1)).all())
+    stones = (obs != 0).sum(-1)
+    assert int(stones.max()) <= n * n and int(done.sum()) == 0          # no 11x11 game ends within 8 steps
+    st = _np(env.episode_stats())
+    assert st[2] == 0
+    sh = hx.HexVecEnv(n, E // 8, env_offset=7 * E // 8, **kw)
+    o2 = (sh.rollout_random if two else sh.rollout_selfplay)(T)
+    for k in ("obs", "legal", "actions", "reward", "done"):
+        assert torch.equal(o1[k][:, 7 * E // 8:], o2[k]), k
+    Eo = 512
+    o = ho.OracleVec(n, Eo, seed=2, flags=_flags("B", two, None, True, 0), env_offset=7 * E // 8)
+    if two:
+        oobs, olegal, oact, orew, odone = o.rollout(T)
+        assert np.array_equal(_np(o2["obs"][:, :Eo]), oobs) and np.array_equal(_np(o2["actions"][:, :Eo]), oact)
+    else:
+        for t in range(T):
+            oo, ol, orw, od, ow = o.step()
+            assert np.array_equal(_np(o2["obs"][t, :Eo]), oo), t
+            assert np.array_equal(_np(o2["reward"][t, :Eo]), orw), t

@@ -428,13 +428,56 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
 
 
+def _bench_under_launcher(nranks):
+    """bench.py as the driver starts it for N > 1: one process per GPU under torch.distributed.run,
+    RCCL ("nccl") process group; the launcher is a child process, so it starts before any GPU call
+    of its own"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + 17 * nranks),
+           os.path.join(root, "bench.py"), "--gpus", str(nranks), "--steps", "20", "--warmup", "5",
+           "--envs", "8192", "--no-cpu", "--no-host-stepped", "--no-w2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == nranks and d["config"]["global_envs"] == 8192 * nranks
+    assert d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - nranks * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    return d
+
+
+def test_bench_under_torch_distributed_run_one_rank():
+    """the N = 1 case of the multi-GPU launch path: RCCL initialises, the stats all_gather and the
+    max-over-ranks all_reduce run on the device"""
+    d = _bench_under_launcher(1)
+    assert d["episodes"]["n"] > 0
+
+
+def test_bench_two_ranks_over_rccl():
+    """two ranks, two GPUs (skipped on a one-GPU box; torch.cuda.device_count() does not touch the GPU)"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _bench_under_launcher(2)
+    assert d["episodes"]["n"] > 0
+
+
 def test_collect_step_as_one_hip_graph(hx):
-    """policy forward + env step + opponent networks captured once and replayed; invariants hold"""
+    """policy forward + env step + opponent networks captured once and replayed; invariants hold.
+    Two DISTINCT opponent networks are in play (pool vs best), so the slot-dependent member masks
+    are part of the replayed graph; no sampling row is ever degenerate and no step ends illegally."""
     from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
     n, E = 7, 2048
     torch.manual_seed(0)
-    agent, opp = MlpActorPolicy(n * n).to("cuda"), MlpActorPolicy(n * n).to("cuda")
+    agent, opp, opp2 = (MlpActorPolicy(n * n).to("cuda") for _ in range(3))
     env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=5, base_model=opp, seed=4)
+    env.set_opponent_model(2, opp2, 0.5)            # pool slot 2 AND best model: a second policy group
+    assert env.best_model is opp2 and len(env._groups()) == 2
     env.reset()
     col = env.vec.agent_colours()
     run = env.capture_collect_step(agent)
@@ -446,5 +489,64 @@ def test_collect_step_as_one_hip_graph(hx):
         assert torch.equal(legal, (o == 0).to(torch.uint8))
         own, other = (o == -1).sum(1), (o == 1).sum(1)
         assert torch.equal(own, torch.where(col == 0, other, other - 1))
+        assert int((win == 3).sum()) == 0, k            # nobody ever played an occupied cell
         tot += int(done.sum())
     assert tot > E and _np(env.episode_stats())[2] - before == tot
+    assert env.degenerate_rows(agent) == 0 and run.captures == 1
+
+
+def test_captured_collect_step_follows_the_opponent_pool(hx):
+    """set_opponent_model / set_eval after the capture (the SelfPlayCallback cycle,
+    SelfplayWrapper.py:113-136): the next run() captures again and plays the NEW opponents"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, RandomLegalPolicy
+
+    class Corner:                                   # always answers with the first / last empty cell
+        def __init__(self, last):
+            self.last, self.calls = last, 0
+
+        def choose_actions(self, obs, legal):
+            self.calls += 1
+            idx = torch.arange(legal.shape[1], device=legal.device).expand_as(legal)
+            key = torch.where(legal != 0, idx, torch.full_like(idx, -1 if self.last else 10 ** 6))
+            return key.argmax(1) if self.last else key.argmin(1)
+
+    n, E = 5, 256
+    first, last = Corner(False), Corner(True)
+    env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=3, base_model=first, agent_player_num=0, seed=9)
+    env.reset()
+    agent = RandomLegalPolicy(env._gen)
+    run = env.capture_collect_step(agent)
+    def opp_positions(obs):         # cells of the opponent's stones (+1 for a BLACK agent) in ITS row-major order
+        o = obs.reshape(E, n, n).transpose(1, 2).reshape(E, -1) == 1
+        idx = torch.arange(n * n, device=o.device).expand_as(o)
+        return (torch.where(o, idx, torch.full_like(idx, n * n)).amin(1),
+                torch.where(o, idx, torch.full_like(idx, -1)).amax(1))
+
+    lo, hi = opp_positions(run()[0])            # 3 warm-up steps + 1 replay: <= 8 stones on a board
+    assert bool((hi >= 0).all()) and bool((hi < 8).all())       # "first empty cell" opponents everywhere
+    for k in range(3):
+        env.set_opponent_model(k, last, 1.0 + k)    # replaces the pool and the best model
+    calls = last.calls
+    env.reset()
+    lo, hi = opp_positions(run()[0])
+    assert run.captures == 2 and last.calls > calls
+    assert bool((lo >= n * n - 8).all()) and bool((lo < n * n).all())   # "last empty cell" opponents now
+    env.set_eval(True)
+    run()
+    assert run.captures == 3
+    env.set_eval(False)
+    run()
+    assert run.captures == 4 and env.degenerate_rows(agent) == 0
+
+
+def test_default_random_pool_is_one_policy_group(hx):
+    """base_model=None (the reference's default, SelfplayWrapper.py:58-60): buffer_size + 1 random
+    policies, identical and stateless -> ONE batched call per opponent round"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv
+    env = VecSelfPlayEnv(board_size=5, num_envs=64, buffer_size=20, seed=1)
+    assert len(env._groups()) == 1
+    env.reset()
+    for _ in range(30):
+        a = env.best_model.choose_actions(env.vec.obs, env.vec.legal)
+        env.step(a)
+    assert env.degenerate_rows() == 0
