@@ -3,70 +3,115 @@
 The reference's engines are plain numpy objects (HexGame.py:16-142,
 HexSingleGame.py:21-153).  Here the state lives on the GPU in a one-env,
 exact-label libhexvec handle; every `make_move` is one literal ply
-(`hexvec_apply_moves`, T = 1) followed by a read-back, so the attributes the
-reference exposes (.board, .regions, .done, .winner, .current_player_num)
-are always those of the reference on the same move sequence.
-"""
-import numpy as np
+(`hexvec_apply_moves`, T = 1), so the attributes the reference exposes
+(.board, .regions, .done, .winner, .current_player_num) are always those of
+the reference on the same move sequence.
 
+A ply costs ONE kernel launch and ONE wait: the action and every output (return
+code, done, reward, legal mask, board) live in host-pinned buffers that the
+kernel reads and writes directly over the bus -- no device allocation, no copy
+call; `hexvec_stream_synchronize` is the only blocking call.  regions and
+current_player_num are fetched (same way) only when somebody asks for them.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
 from .vec_env import HexVecEnv
+
+
+def _pinned(shape, dtype):
+    t = torch.empty(shape, dtype=dtype, pin_memory=True)
+    return t, t.numpy(), C.c_void_p(t.data_ptr())
 
 
 class _BoardEngine:
     """encoding 'A': engine plies; encoding 'B': env-B steps (make_move + inversion)."""
 
     def __init__(self, board_size, encoding, device=None):
-        self.n = int(board_size)
+        self.n = n = int(board_size)
         self.encoding = encoding
-        self.env = HexVecEnv(self.n, 1, device=device, encoding=encoding, two_sided=True,
+        self.env = HexVecEnv(n, 1, device=device, encoding=encoding, two_sided=True,
                              auto_reset=False)
-        self._board = None
-        self._legal = None
-        self._sync()
+        self._L, self._h = self.env._L, self.env._h
+        cells, padded = n * n, (n + 2) ** 2
+        # host-pinned I/O, written / read by the kernels themselves
+        self._t_act, self._act, self._p_act = _pinned((1, 1), torch.int32)
+        self._t_ret, self._ret, self._p_ret = _pinned((1, 1), torch.int8)
+        self._t_done, self._done, self._p_done = _pinned((1, 1), torch.uint8)
+        self._t_rb, self._rb, self._p_rb = _pinned((1, 1), torch.int8)
+        self._t_lg, self._lg, self._p_lg = _pinned((cells,), torch.uint8)
+        self._t_ob, self._ob, self._p_ob = _pinned((cells,), torch.int8)
+        self._t_lab, self._lab, self._p_lab = _pinned((2 * padded,), torch.uint8)
+        self._t_cur, self._curb, self._p_cur = _pinned((1,), torch.uint8)
+        self._t_bin, self._bin, self._p_bin = _pinned((cells,), torch.int8)
+        self._t_lin, self._lin, self._p_lin = _pinned((2 * padded,), torch.uint8)
+        self._empty = 2 if encoding == "A" else 0
+        self._board = self._legal = self._labels = self._cur = None
+        self._st = self.env._stream()   # every call below ends in a wait, so one fixed stream is enough
+        self._fetch_board()
 
     # -- state transfer -------------------------------------------------
-    def _sync(self):
-        board, labels, cur = self.env.get_state()
-        self._board = board.cpu().numpy().reshape(self.n, self.n).astype(np.float64)
-        self._labels = labels.cpu().numpy().reshape(2, self.n + 2, self.n + 2).astype(np.float64)
-        self._cur = int(cur.cpu().numpy()[0])
-        empty = 2 if self.encoding == "A" else 0
-        self._legal = (self._board.ravel() == empty)
+    def _wait(self):
+        rc = self._L.hexvec_stream_synchronize(self._h, self._st)
+        if rc:
+            _lib.check(rc)
+
+    def _fetch_board(self):
+        """board + labels + player to move of the current position (after a reset / set_position)"""
+        _lib.check(self._L.hexvec_get_state(self._h, self._p_ob, self._p_lab, self._p_cur, self._st))
+        self._wait()
+        self._board = self._legal = None
+        self._labels = self._lab.reshape(2, self.n + 2, self.n + 2).astype(np.float64)
+        self._cur = int(self._curb[0])
+        self._lg[:] = self._ob == self._empty
 
     def set_position(self, board, regions, cur):
-        b = np.asarray(board).astype(np.int8).reshape(1, -1)
-        lab = None if regions is None else np.asarray(regions).astype(np.uint8).reshape(1, -1)
-        self.env.set_state(b, lab, cur)
-        self._sync()
+        self._bin[:] = np.asarray(board).reshape(-1)
+        lab = None
+        if regions is not None:
+            self._lin[:] = np.asarray(regions).reshape(-1)
+            lab = self._p_lin
+        _lib.check(self._L.hexvec_set_state(self._h, self._p_bin, lab, int(cur), self._st))
+        self._fetch_board()
 
     def ply(self, action):
         """one literal ply; returns (ret code, done flag, reward[0])"""
-        ret, done, rb, legal, obs = self.env.apply_moves(np.array([[int(action)]], np.int32))
-        ret = int(ret.cpu().numpy()[0, 0])
-        done = bool(done.cpu().numpy()[0, 0])
-        rb = int(rb.cpu().numpy()[0, 0])
-        self._board = obs.cpu().numpy().reshape(self.n, self.n).astype(np.float64)
-        self._legal = legal.cpu().numpy().reshape(-1).astype(bool)
-        self._labels = None
-        self._cur = None
-        return ret, done, rb
+        self._act[0, 0] = action
+        _lib.check(self._L.hexvec_apply_moves(self._h, self._p_act, 1, self._p_ret, self._p_done, self._p_rb,
+                                              self._p_lg, self._p_ob, self._st))
+        self._wait()
+        self._board = self._legal = self._labels = self._cur = None
+        return int(self._ret[0, 0]), bool(self._done[0, 0]), int(self._rb[0, 0])
 
     @property
     def board(self):
+        if self._board is None:     # float64 like the reference's numpy boards (a fresh array per position)
+            self._board = self._ob.reshape(self.n, self.n).astype(np.float64)
         return self._board
 
     @property
     def legal(self):
+        if self._legal is None:
+            self._legal = self._lg.astype(bool)
         return self._legal
+
+    def _fetch_labels(self):
+        _lib.check(self._L.hexvec_get_state(self._h, None, self._p_lab, self._p_cur, self._st))
+        self._wait()
+        self._labels = self._lab.reshape(2, self.n + 2, self.n + 2).astype(np.float64)
+        self._cur = int(self._curb[0])
 
     @property
     def regions(self):
         if self._labels is None:
-            self._sync()
+            self._fetch_labels()
         return self._labels
 
     @property
     def cur(self):
         if self._cur is None:
-            self._sync()
+            self._fetch_labels()
         return self._cur

@@ -509,6 +509,14 @@ extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
     return HEXVEC_OK;
 }
 
+extern "C" int hexvec_stream_synchronize(hexvec_t *h, void *stream)
+{
+    HV_HANDLE(h);
+    HV_DEVICE(h);
+    HV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return HEXVEC_OK;
+}
+
 extern "C" int hexvec_board_size(const hexvec_t *h) { return h ? h->N : HEXVEC_E_ARG; }
 extern "C" int hexvec_num_envs(const hexvec_t *h) { return h ? h->E : HEXVEC_E_ARG; }
 extern "C" uint32_t hexvec_flags(const hexvec_t *h) { return h ? h->flags : 0u; }

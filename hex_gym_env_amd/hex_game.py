@@ -139,7 +139,10 @@ class HexEnv(gym.Env):
         return player((self.player + 1) % 2)
 
     def get_action_mask(self):
-        return np.array([self.simulator.is_valid_move(a) for a in range(self.board_size ** 2)])
+        # == np.array([is_valid_move(a) for a in range(N*N)]) (HexGame.py:203-204); the kernel wrote it
+        if self.simulator._board_override is not None:
+            return (np.asarray(self.simulator.board).ravel() == player.EMPTY)
+        return self.simulator._eng.legal.copy()
 
     def reset(self, seed=None, options=None):
         regions = None if self.initial_regions is None else self.initial_regions.copy()

@@ -200,6 +200,13 @@ size_t hexvec_state_bytes(const hexvec_t *h);
 int hexvec_export_state(hexvec_t *h, void *dst, void *stream);
 int hexvec_import_state(hexvec_t *h, const void *src, void *stream);
 
+/* Blocks the calling thread until everything enqueued on `stream` (NULL = default stream) has
+ * finished (hipStreamSynchronize on the handle's device): the one blocking call of the ABI, for
+ * callers that hand the library HOST-PINNED output buffers (hipHostMalloc / torch pin_memory: the
+ * kernels write them directly, no copy) and read them right after -- the single-board mirrors of
+ * HexGame.make_move (HexGame.py:85-111) do exactly that, one launch + one wait per ply. */
+int hexvec_stream_synchronize(hexvec_t *h, void *stream);
+
 int hexvec_board_size(const hexvec_t *h);
 int hexvec_num_envs(const hexvec_t *h);
 uint32_t hexvec_flags(const hexvec_t *h);
