@@ -72,8 +72,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-host-stepped", action="store_true")
     ap.add_argument("--no-w2", action="store_true", help="skip the two-sided rollout leg")
-    ap.add_argument("--layout", choices=["rollout", "bitboard"], default="rollout",
-                    help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT)")
+    ap.add_argument("--layout", choices=["auto", "rollout", "bitboard"], default="auto",
+                    help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT); "
+                         "auto = by the number of wavefronts the geometry gives (HexVecEnv rollout_layout='auto')")
     ap.add_argument("--reps", type=int, default=0, help="timed repetitions of the --steps region (0 = auto, >= 20)")
     ap.add_argument("--warmup-internal-ms", type=float, default=30.0)
     args = ap.parse_args()
@@ -103,7 +104,7 @@ def main():
     # the rollout handle keeps its state in the rollout layout (HEXVEC_F_ROLLOUT_LAYOUT: lane-per-board
     # union-find); --layout bitboard runs the same rollout on the default (host-stepping) layout
     env = hx.HexVecEnv(N, E, device=dev, encoding="B", seed=0, env_offset=rank * E,
-                       rollout_layout=args.layout == "rollout")
+                       rollout_layout={"auto": "auto", "rollout": True, "bitboard": False}[args.layout])
     out = dict(obs=torch.empty((T, E, C), dtype=torch.int8, device=dev),
                legal=torch.empty((T, E, C), dtype=torch.uint8, device=dev),
                actions=torch.empty((T, E), dtype=torch.int32, device=dev),
@@ -213,7 +214,7 @@ def main():
     if not args.no_w2:
         del out
         env2 = hx.HexVecEnv(N, E, device=dev, encoding="B", two_sided=True, seed=1, env_offset=rank * E,
-                            rollout_layout=args.layout == "rollout")
+                            rollout_layout={"auto": "auto", "rollout": True, "bitboard": False}[args.layout])
         T2 = 64
         out2 = dict(obs=torch.empty((T2, E, C), dtype=torch.int8, device=dev),
                     legal=torch.empty((T2, E, C), dtype=torch.uint8, device=dev),

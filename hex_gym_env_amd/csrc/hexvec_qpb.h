@@ -12,8 +12,8 @@
 //                 their own frame and share the six hex offsets).
 //
 // A ply of colour p at cell a (HexGame.py:85-111, HexSingleGame.py:88-122):  nb = the six neighbours of
-// a (one masked multi-word shift per direction: a shift moves bits between the words of a board with one
-// DPP row shift); the stone touches the top iff a is in row 0 or nb meets T, the bottom likewise; the
+// a (one funnel shift + destination mask per direction; two DPP row shifts fetch the neighbouring
+// words of the board); the stone touches the top iff a is in row 0 or nb meets T, the bottom likewise; the
 // mover has connected its edges iff both hold -- that is the reference's test regions[p][-1,-1] == 1
 // after flood_fill (HexGame.py:98-105; plain connectivity).  A stone that touches an edge set
 // drags its floating component into that set: a frontier flood over S & ~(T|D), one dilation per level
@@ -133,27 +133,27 @@ template <int N, int ENC> struct Q {
         if (L >= 16) x |= dpp0<DPP_ROW_MIRROR>(x);
         return x;
     }
-    // Multi-word shifts of a bitboard by S cells.  The callers mask the source so that no bit
-    // leaves the board, hence nothing is carried out of a group (or out of its DPP row).
-    template <int S> static __device__ __forceinline__ u32 shl_cells(u32 m)
-    {
-        u32 r = m << S;
-        if (L > 1) r |= dpp0<DPP_ROW_SHR1>(m >> (32 - S));
-        return r;
-    }
-    template <int S> static __device__ __forceinline__ u32 shr_cells(u32 m)
-    {
-        u32 r = m >> S;
-        if (L > 1) r |= dpp0<DPP_ROW_SHL1>(m << (32 - S));
-        return r;
-    }
     // the six hex neighbours (-1,0) (-1,+1) (0,-1) (0,+1) (+1,-1) (+1,0) of every cell of m
-    // (HexGame.py:128-131: the 3x3 neighbourhood without [0,0] and [2,2])
+    // (HexGame.py:128-131: the 3x3 neighbourhood without [0,0] and [2,2]).
+    // A shift by S cells is one funnel shift (v_alignbit) over the lane's word and its neighbour's
+    // (ONE DPP row shift per direction of travel serves all three shifts that way); what a shift
+    // drags across a row end, a board end or in from the neighbouring board lands only on cells the
+    // DESTINATION mask of that direction clears (m_l: column > 0, m_up: row > 0, ...; for a shift
+    // towards higher cells the stray bits fall into row 0 or column 0, towards lower cells into
+    // row N-1, column N-1 or the padding), so the source needs no masking.
     static __device__ __forceinline__ u32 dilate(u32 m, const LC &c)
     {
-        u32 r = shl_cells<1>(m & c.m_r) | shr_cells<1>(m & c.m_l);
-        r |= shl_cells<N>(m & c.m_dn) | shr_cells<N>(m & c.m_up);
-        if (N > 1) r |= shl_cells<(N > 1 ? N - 1 : 1)>(m & c.m_dl) | shr_cells<(N > 1 ? N - 1 : 1)>(m & c.m_ur);
+        if (L == 1) {
+            return ((m << 1) & c.m_l) | ((m >> 1) & c.m_r) | ((m << N) & c.m_up) | ((m >> N) & c.m_dn) |
+                   ((m << (N - 1)) & c.m_ur) | ((m >> (N - 1)) & c.m_dl);
+        }
+        const u32 prev = dpp0<DPP_ROW_SHR1>(m), next = dpp0<DPP_ROW_SHL1>(m); // word l-1 / l+1 of the board
+        u32 r = __builtin_amdgcn_alignbit(m, prev, 31) & c.m_l;                // +1
+        r |= __builtin_amdgcn_alignbit(next, m, 1) & c.m_r;                    // -1
+        r |= __builtin_amdgcn_alignbit(m, prev, 32 - N) & c.m_up;              // +N
+        r |= __builtin_amdgcn_alignbit(next, m, N) & c.m_dn;                   // -N
+        r |= __builtin_amdgcn_alignbit(m, prev, 32 - (N - 1)) & c.m_ur;        // +(N-1): (y+1, x-1)
+        r |= __builtin_amdgcn_alignbit(next, m, N - 1) & c.m_dl;               // -(N-1): (y-1, x+1)
         return r;
     }
 

@@ -62,6 +62,11 @@ class HexVecEnv:
             flags |= _lib.F_NO_AUTO_RESET
         if exact_labels:
             flags |= _lib.F_EXACT_LABELS
+        if rollout_layout == "auto":
+            # The lane-per-board layout runs one playing wavefront per 64 boards and needs about one per
+            # SIMD (1 024 on MI355X) to win; below ~3/4 of that the bitboard kernels (4x the wavefronts at
+            # 9x9..11x11) fill the chip better (measured: DESIGN.md, occupancy table).
+            rollout_layout = (num_envs + 63) // 64 >= 768
         if rollout_layout:      # state laid out for rollout_selfplay / rollout_random (include/hexvec.h)
             flags |= _lib.F_ROLLOUT_LAYOUT
         # auto-reset handles run on the bitboard / lane-per-board kernels (include/hexvec.h)

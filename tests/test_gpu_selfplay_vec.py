@@ -407,7 +407,8 @@ def test_bench_json_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "10",
-                          "--envs", "8192", "--chunk", "20", "--cpu-seconds", "1.5"], capture_output=True, text=True, timeout=600)
+                          "--envs", "8192", "--chunk", "20", "--cpu-seconds", "1.5", "--layout", "rollout"],
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
