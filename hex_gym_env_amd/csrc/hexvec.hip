@@ -1,6 +1,6 @@
 // hexvec.hip -- host side of libhexvec: the C ABI of include/hexvec.h.
 // Kernels: hexvec_wpb.hip (wave-per-board, literal engine), hexvec_qpb_{s,m,l}.hip (lanes-per-board
-// bitboards, the throughput path; hexvec_qpb.h), hexvec_lpb64.hip / hexvec_lpb32.hip (lane-per-board
+// bitboards, the throughput path; hexvec_qpb.h), hexvec_lpb64.hip (lane-per-board
 // union-find in LDS, the round-1 throughput path, the layout of HEXVEC_F_ROLLOUT_LAYOUT handles).
 #include <stdlib.h>
 
@@ -18,7 +18,6 @@ struct hexvec {
     int *stats;
     bool fast_mode;      // throughput kernels + fast state (auto-reset handles)
     bool qpb;            // fast_mode: bitboard kernels (hexvec_qpb.h); else the LDS union-find ones (hexvec_lpb.h)
-    int bpw;             // lpb: boards per wavefront (64 or 32)
     unsigned char *fast;
     size_t fast_bytes;
 };
@@ -124,8 +123,7 @@ static int run(hexvec *h, int mode, const KArgs &a, void *stream)
         HV_HIP(HV_QPB_CALL(h->N, launch, h->N, enc, mode, a, (hipStream_t)stream));
     } else if (h->fast_mode) {
         g_kernel = lpb_kname(mode);
-        HV_HIP(h->bpw == 32 ? lpb32_launch(h->N, enc, mode, a, (hipStream_t)stream)
-                            : lpb64_launch(h->N, enc, mode, a, (hipStream_t)stream));
+        HV_HIP(lpb64_launch(h->N, enc, mode, a, (hipStream_t)stream));
     } else {
         g_kernel = kname(mode);
         HV_HIP(wpb_launch(h->N, enc, mode, a, (hipStream_t)stream));
@@ -168,10 +166,6 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     h->fast_mode = !(flags & (HEXVEC_F_NO_AUTO_RESET | HEXVEC_F_EXACT_LABELS)) && board_size >= 4;
     const size_t E = (size_t)num_envs;
     bool ok;
-    // 64 boards per wave by default; 32 (two waves per SIMD, half-waves in the per-lane part)
-    // measured within 2 % of it on MI355X and stays selectable for experiments
-    h->bpw = 64;
-    if (const char *ev = getenv("HEXVEC_BPW")) h->bpw = atoi(ev) == 32 ? 32 : (atoi(ev) == 64 ? 64 : h->bpw);
     h->qpb = !(flags & HEXVEC_F_ROLLOUT_LAYOUT);
     if (const char *ev = getenv("HEXVEC_FAMILY")) // A/B experiments
         h->qpb = strcmp(ev, "lpb") == 0 ? false : (strcmp(ev, "qpb") == 0 ? true : h->qpb);
@@ -181,10 +175,8 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
         h->fast_bytes = bytes;
         ok = hipMalloc(&h->fast, bytes) == hipSuccess;
     } else if (h->fast_mode) {
-        const int enc = (flags & HEXVEC_F_ENC_B) ? 1 : 0;
-        const size_t bytes = h->bpw == 32
-                                 ? (size_t)((num_envs + 31) / 32) * hv::lpb32_block_bytes(board_size, enc)
-                                 : (size_t)((num_envs + 63) / 64) * hv::lpb64_block_bytes(board_size, enc);
+        const int enc = (flags & HEXVEC_F_ENC_B) ? 1 : 0, two = (flags & HEXVEC_F_TWO_SIDED) ? 1 : 0;
+        const size_t bytes = (size_t)((num_envs + 63) / 64) * hv::lpb64_block_bytes(board_size, enc, two);
         h->fast_bytes = bytes;
         ok = hipMalloc(&h->fast, bytes) == hipSuccess;
     } else {
@@ -374,8 +366,8 @@ extern "C" int hexvec_get_state(hexvec_t *h, int8_t *board, uint8_t *labels, uin
             return HEXVEC_OK;
         }
         g_kernel = "k_lpb_get_state";
-        HV_HIP(h->bpw == 32 ? hv::lpb32_get_state(h->fast, h->N, enc, h->E, (signed char *)board, cur_player, (hipStream_t)stream)
-                            : hv::lpb64_get_state(h->fast, h->N, enc, h->E, (signed char *)board, cur_player, (hipStream_t)stream));
+        HV_HIP(hv::lpb64_get_state(h->fast, h->N, enc, (h->flags & HEXVEC_F_TWO_SIDED) ? 1 : 0, h->E, (signed char *)board,
+                                   cur_player, (hipStream_t)stream));
         return HEXVEC_OK;
     }
     g_kernel = "k_get_state";
@@ -430,8 +422,8 @@ extern "C" int hexvec_episode_stats(hexvec_t *h, double *out4, void *stream)
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
-        HV_HIP(h->bpw == 32 ? hv::lpb32_stats(h->fast, h->N, enc, h->E, out4, nullptr, (hipStream_t)stream)
-                            : hv::lpb64_stats(h->fast, h->N, enc, h->E, out4, nullptr, (hipStream_t)stream));
+        HV_HIP(hv::lpb64_stats(h->fast, h->N, enc, (h->flags & HEXVEC_F_TWO_SIDED) ? 1 : 0, h->E, out4, nullptr,
+                               (hipStream_t)stream));
         return HEXVEC_OK;
     }
     g_kernel = "k_stats";
@@ -452,8 +444,8 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
     if (h->fast_mode) {
         g_kernel = "k_lpb_stats";
         const int enc = (h->flags & HEXVEC_F_ENC_B) ? 1 : 0;
-        HV_HIP(h->bpw == 32 ? hv::lpb32_stats(h->fast, h->N, enc, h->E, nullptr, out, (hipStream_t)stream)
-                            : hv::lpb64_stats(h->fast, h->N, enc, h->E, nullptr, out, (hipStream_t)stream));
+        HV_HIP(hv::lpb64_stats(h->fast, h->N, enc, (h->flags & HEXVEC_F_TWO_SIDED) ? 1 : 0, h->E, nullptr, out,
+                               (hipStream_t)stream));
         return HEXVEC_OK;
     }
     g_kernel = "k_agents";

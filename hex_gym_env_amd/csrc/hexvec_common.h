@@ -84,18 +84,11 @@ hipError_t wpb_stats(const int *stats, int E, double *out4, hipStream_t st);
 hipError_t wpb_agents(const u32 *hot, int E, unsigned char *out, hipStream_t st);
 
 hipError_t lpb64_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
-size_t lpb64_block_bytes(int N, int enc);
-hipError_t lpb64_get_state(const unsigned char *fast, int N, int enc, int E, signed char *board,
+size_t lpb64_block_bytes(int N, int enc, int two);
+hipError_t lpb64_get_state(const unsigned char *fast, int N, int enc, int two, int E, signed char *board,
                            unsigned char *cur, hipStream_t st);
-hipError_t lpb64_stats(const unsigned char *fast, int N, int enc, int E, double *out4,
+hipError_t lpb64_stats(const unsigned char *fast, int N, int enc, int two, int E, double *out4,
                        unsigned char *agents, hipStream_t st);
-hipError_t lpb32_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
-size_t lpb32_block_bytes(int N, int enc);
-hipError_t lpb32_get_state(const unsigned char *fast, int N, int enc, int E, signed char *board,
-                           unsigned char *cur, hipStream_t st);
-hipError_t lpb32_stats(const unsigned char *fast, int N, int enc, int E, double *out4,
-                       unsigned char *agents, hipStream_t st);
-
 
 // lanes-per-board bitboard kernels (hexvec_qpb.h), one translation unit per size range
 #define HV_QPB_DECL(x)                                                                                        \

@@ -21,12 +21,18 @@
 //                     verified equals the reference's label merging
 //                     (HexGame.py:124-142 + :101-105).
 //   IMG[v][board][C]  the observation bytes themselves, packed exactly as the
-//                     [E, N*N] output rows: v=0 the BLACK-to-move view, v=1
-//                     (encoding B) the WHITE-to-move view -F^T
-//                     (HexSingleGame.py:265-271).  A ply writes one byte in
-//                     each.  Emitting obs + legal mask for 64 boards is a
-//                     wave-cooperative copy LDS -> HBM with 16-byte loads and
-//                     stores of whole contiguous spans (64*C bytes per view).
+//                     [E, N*N] output rows.  Encoding B shows the board in the
+//                     mover's perspective (HexSingleGame.py:265-271: BLACK to move
+//                     sees F, WHITE to move sees -F^T).  Two-sided handles keep both
+//                     views (VIEWS = 2: v=0 BLACK-to-move, v=1 WHITE-to-move; a ply
+//                     writes one byte in each); self-play handles keep ONE image per
+//                     board, in the view of that board's AGENT (VIEWS = 1) -- the only
+//                     view a self-play step ever returns; the rare other view (the
+//                     opponent's, in the split step / a terminal observation) is read
+//                     out of it as the negated transpose.  That halves the image (13x13 and
+//                     14x14 at 65 536 boards fit the LDS in one pass).  Emitting obs + legal
+//                     mask for 64 boards is a wave-cooperative copy LDS -> HBM with
+//                     16-byte loads and stores of whole contiguous spans.
 //
 // Empty-cell bitboards (one per frame) stay in registers for the uniform
 // random policy (k-th set bit) and the legality test.  Scalars (action,
@@ -37,9 +43,8 @@
 // quirks (q1/q2 of SURVEY 8a) cannot be observed; handles created with
 // HEXVEC_F_NO_AUTO_RESET or HEXVEC_F_EXACT_LABELS use the wave-per-board
 // kernels, which keep the reference's label planes bit for bit.
-// Included by hexvec_lpb64.hip / hexvec_lpb32.hip with HV_BPW = boards per wavefront
-// (64: every lane owns a board; 32: the upper half-wave only helps in the cooperative
-// copies, LDS per wave halves and two waves fit per SIMD) and HV_LPB_NAME(x) = lpbNN_##x.
+// Included by hexvec_lpb64.hip with HV_BPW = 64 boards per wavefront (every lane owns a board;
+// 32 was measured in round 1: same time, the per-lane part doubles) and HV_LPB_NAME(x) = lpb64_##x.
 #pragma once
 #include "hexvec_common.h"
 
@@ -64,10 +69,12 @@ template <int N> struct Regs {
     static constexpr int REGW = 2 * JW + 8;
 };
 
-template <int N, int ENC, int BPW> struct Lpb {
+template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
     using G = Geo<N, BPW>;
     static constexpr bool B = ENC == 1;
-    static constexpr int NV = B ? 2 : 1;
+    static constexpr int NV = B ? VIEWS : 1;
+    static constexpr bool TWOV = B && VIEWS == 2; // both views kept
+    static constexpr bool ONE = B && VIEWS == 1;  // one image per board, in its agent's view
     static constexpr int C = G::C, JW = G::JW, PS = G::PS;
     static constexpr int IMG = G::UF_BYTES; // byte offset of IMG[0] in LDS
     static constexpr int LDS_BYTES = G::UF_BYTES + NV * G::IMG_BYTES;
@@ -176,6 +183,19 @@ template <int N, int ENC, int BPW> struct Lpb {
         s.prewon = 0;
     }
 
+    // the image byte(s) of a new stone of colour p
+    static __device__ __forceinline__ void put_stone(unsigned char *lds, const LS &s, int idx0, int idx1, int p, int lane)
+    {
+        if (TWOV) {
+            lds[IMG + lane * C + idx0] = p ? 1 : 0xFF;                 // view 0:  F, BLACK -1 / WHITE +1
+            lds[IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;  // view 1: -F^T
+        } else if (ONE) { // the agent's view: its own stones read -1
+            lds[IMG + lane * C + (s.agent ? idx1 : idx0)] = p == s.agent ? 0xFF : 1;
+        } else {
+            lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
+        }
+    }
+
     // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
     // true iff p now connects its two edges (HexGame.py:98-105 via connectivity).
     static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int y, int x,
@@ -203,12 +223,7 @@ template <int N, int ENC, int BPW> struct Lpb {
         clear_bit(s.E0, idx0);
         clear_bit(s.E1, idx1);
         s.n_empty -= 1;
-        if (B) {
-            lds[IMG + lane * C + idx0] = p ? 1 : 0xFF;                 // view 0:  F, BLACK -1 / WHITE +1
-            lds[IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;  // view 1: -F^T
-        } else {
-            lds[IMG + lane * C + idx0] = (unsigned char)p;             // absolute 0 / 1 (EMPTY 2)
-        }
+        put_stone(lds, s, idx0, idx1, p, lane);
         // follow child pointers to the roots (all six chains of all lanes together)
         for (;;) {
             bool any = false;
@@ -267,14 +282,25 @@ template <int N, int ENC, int BPW> struct Lpb {
     }
 
     // wave-cooperative: rows of the boards in `mask` -> dst[(board) * C ...] (terminal observations)
-    static __device__ __forceinline__ void copy_rows(const unsigned char *lds, u64 mask, u64 view1, signed char *dst, int lane)
+    // (agent1: bit d = board d's agent plays WHITE = the view its single image is kept in)
+    static __device__ __forceinline__ void copy_rows(const unsigned char *lds, u64 mask, u64 view1, u64 agent1,
+                                                     signed char *dst, int lane)
     {
         while (mask) {
             const int d = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int v = B ? (int)((view1 >> d) & 1) : 0;
-            for (int i = lane; i < C; i += 64)
-                dst[(size_t)d * C + i] = (signed char)lds[IMG + v * G::IMG_BYTES + d * C + i];
+            if (ONE) {
+                const bool flip = ((view1 ^ agent1) >> d) & 1; // the other view: negated transpose
+                for (int i = lane; i < C; i += 64) {
+                    u32 x = lds[IMG + d * C + (flip ? transpose(i) : i)];
+                    x = (flip && x) ? x ^ 0xFEu : x;
+                    dst[(size_t)d * C + i] = (signed char)x;
+                }
+            } else {
+                const int v = TWOV ? (int)((view1 >> d) & 1) : 0;
+                for (int i = lane; i < C; i += 64)
+                    dst[(size_t)d * C + i] = (signed char)lds[IMG + v * G::IMG_BYTES + d * C + i];
+            }
         }
     }
 
@@ -283,7 +309,9 @@ template <int N, int ENC, int BPW> struct Lpb {
                                                      uint4 &o, uint4 &l)
     {
         o = r0;
-        if (B) {
+        if (ONE) { // the image is the view: values 0x00 / 0x01 / 0xFF, empty <=> bit 0 clear
+            l = make_uint4(~o.x & 0x01010101u, ~o.y & 0x01010101u, ~o.z & 0x01010101u, ~o.w & 0x01010101u);
+        } else if (B) {
             const int b0 = byte0 / C;
             const int s = C - (byte0 - b0 * C); // bytes [0,s) of this vector belong to board b0
             const u32 ph = (u32)(view1 >> b0);
@@ -309,7 +337,7 @@ template <int N, int ENC, int BPW> struct Lpb {
     {
         const uint4 r0 = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
         uint4 r1 = r0;
-        if (B) r1 = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+        if (TWOV) r1 = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
         merge_vec(view1, byte0, r0, r1, o, l);
     }
 
@@ -347,7 +375,7 @@ template <int N, int ENC, int BPW> struct Lpb {
         for (int it = 0; it < G::NIT; ++it) {
             const int byte0 = min((it * 64 + lane) * 16, G::IMG_BYTES - 16);
             sn.r0[it] = *reinterpret_cast<const uint4 *>(lds + IMG + byte0);
-            if (B) sn.r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
+            if (TWOV) sn.r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
         }
     }
     template <bool OBS, bool LEGAL>
@@ -358,7 +386,7 @@ template <int N, int ENC, int BPW> struct Lpb {
         for (int it = 0; it < G::NIT; ++it) {
             const int byte0 = (it * 64 + lane) * 16;
             uint4 o, l;
-            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], B ? sn.r1[it] : sn.r0[it], o, l);
+            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], TWOV ? sn.r1[it] : sn.r0[it], o, l);
             if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
                 // streamed once, never re-read by this kernel: non-temporal stores
                 typedef u32 __attribute__((ext_vector_type(4))) v4u;
@@ -377,10 +405,32 @@ template <int N, int ENC, int BPW> struct Lpb {
     // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`.
     // All LDS reads of the span are issued first, then merged and stored as whole 1 KiB pieces;
     // only the last piece is partial (lanes past the span re-read the last vector and skip the store).
-    static __device__ __forceinline__ void emit(const unsigned char *lds, u64 view1, signed char *obs,
+    // one-image boards asked for their OTHER view (flip bit set): bytes gathered through the transpose
+    static __device__ __noinline__ void emit_gather(const unsigned char *lds, u64 flip, signed char *obs,
+                                                    unsigned char *legal, int live_bytes, int lane)
+    {
+#pragma unroll 1
+        for (int j = lane; j < live_bytes; j += 64) {
+            const int b = j / C, i = j - b * C;
+            const bool f = (flip >> b) & 1;
+            u32 x = lds[IMG + b * C + (f ? transpose(i) : i)];
+            x = (f && x) ? x ^ 0xFEu : x;
+            if (obs) obs[j] = (signed char)x;
+            if (legal) legal[j] = x == 0u;
+        }
+    }
+    static __device__ __forceinline__ void emit(const unsigned char *lds, u64 view1, u64 agent1, signed char *obs,
                                                 unsigned char *legal, int nlive, bool vec_ok, int lane)
     {
         if (!obs && !legal) return;
+        if (ONE) {
+            const u64 livem = nlive >= 64 ? ~0ull : ((1ull << nlive) - 1ull);
+            const u64 flip = (view1 ^ agent1) & livem;
+            if (flip) {
+                emit_gather(lds, flip, obs, legal, nlive * C, lane);
+                return;
+            }
+        }
         if (!(vec_ok && nlive == BPW)) {
             emit_slow(lds, view1, obs, legal, nlive * C, lane);
         } else {
@@ -392,8 +442,8 @@ template <int N, int ENC, int BPW> struct Lpb {
 };
 
 // fast state in HBM, per block of 64 boards: [LDS image][REGW x 64 words]
-template <int N, int ENC, int BPW> struct FastState {
-    using L = Lpb<N, ENC, BPW>;
+template <int N, int ENC, int BPW, int VIEWS> struct FastState {
+    using L = Lpb<N, ENC, BPW, VIEWS>;
     static constexpr int REGW = Regs<N>::REGW;
     static constexpr size_t BLOCK_BYTES = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
 };
@@ -401,10 +451,10 @@ template <int N, int ENC, int BPW> struct FastState {
 // HELPER = 1: 128-thread workgroups.  Wave 0 plays; wave 1 only copies observations: at every emission
 // point wave 0 publishes the view mask and meets wave 1 at a barrier, wave 1 snapshots the images into
 // registers, a second barrier releases wave 0, and wave 1 merges and stores while wave 0 computes on.
-template <int N, int ENC, int MODE, int BPW, int HELPER>
+template <int N, int ENC, int MODE, int BPW, int HELPER, int VIEWS>
 __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 {
-    using L = Lpb<N, ENC, BPW>;
+    using L = Lpb<N, ENC, BPW, VIEWS>;
     using G = Geo<N, BPW>;
     using LS = typename L::LS;
     constexpr bool B = ENC == 1;
@@ -420,7 +470,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     const int env = e0 + lane;
     const bool live = lane < BPW && env < a.E;
     const int nlive = min(BPW, a.E - e0);
-    unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC, BPW>::BLOCK_BYTES;
+    unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
     u32 *rblk = reinterpret_cast<u32 *>(sblk + L::LDS_BYTES);
     const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
     const bool selfplay = !two;
@@ -447,6 +497,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     // helper (barrier 1); emit_release() is the second barrier ("snapshot taken") and is called as
     // late as possible -- right before wave 0 next touches the images -- so that wave 0 draws its
     // next action while the helper reads LDS.
+    u64 agent1 = 0ull; // one-image boards: bit d = board d's image is kept in the WHITE-to-move view
     bool release_owed = false;
     auto emit_release = [&]() {
         if (release_owed) {
@@ -461,7 +512,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             __syncthreads();
             release_owed = true;
         } else {
-            L::emit(lds, view, o, l, nlive, vec_ok, lane);
+            L::emit(lds, view, agent1, o, l, nlive, vec_ok, lane);
         }
     };
 
@@ -505,6 +556,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.se = (int)r[6 * 64 + lane];
         s.sw = (int)r[7 * 64 + lane];
     }
+
+    if (L::ONE) agent1 = __ballot(live && s.agent != 0);
 
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: FT order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
@@ -561,12 +614,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         L::clear_bit(s.E0, idx0);
         L::clear_bit(s.E1, idx1);
         s.n_empty -= 1;
-        if (B) {
-            lds[L::IMG + lane * C + idx0] = p ? 1 : 0xFF;
-            lds[L::IMG + G::IMG_BYTES + lane * C + idx1] = p ? 0xFF : 1;
-        } else {
-            lds[L::IMG + lane * C + idx0] = (unsigned char)p;
-        }
+        L::put_stone(lds, s, idx0, idx1, p, lane);
         const int yp = p == fr ? yf : xf; // row of the stone in p's own frame
         lds[(p * BPW + lane) * L::PS + (p ? idx1 : idx0)] =
             (unsigned char)(0xE0u | (yp == 0 ? 1u : 0u) | (yp == N - 1 ? 2u : 0u));
@@ -578,7 +626,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     auto handle_done = [&](bool dn, int won, signed char *tobs_row) {
         const u64 dmask = __ballot(dn);
         if (!dmask) return;
-        if (tobs_row) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, tobs_row, lane);
+        if (tobs_row) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, agent1, tobs_row, lane);
         L::clear_boards(lds, dmask, lane);
         if (dn) {
             s.sr += s.ep_ret;
@@ -785,36 +833,42 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 }
 
 // ---- cold kernels on the fast state ----
-template <int N, int ENC, int BPW>
+template <int N, int ENC, int BPW, int VIEWS>
 __global__ void k_lpb_get_state(const unsigned char *fast, int E, signed char *board, unsigned char *cur)
 {
-    using L = Lpb<N, ENC, BPW>;
+    using L = Lpb<N, ENC, BPW, VIEWS>;
     constexpr int C = Geo<N, BPW>::C;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)E * (C + 1)) return;
     const int env = (int)(gid / (C + 1)), r = (int)(gid - (long long)env * (C + 1));
     const int blk = env / BPW, lane = env % BPW;
-    const unsigned char *sblk = fast + (size_t)blk * FastState<N, ENC, BPW>::BLOCK_BYTES;
+    const unsigned char *sblk = fast + (size_t)blk * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
     const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
     const int c = (int)(regs[3 * 64 + lane] & 1u);
     if (r < C) {
         if (board) {
-            const int v = (ENC == 1 && c) ? 1 : 0;
-            board[(size_t)env * C + r] = (signed char)sblk[L::IMG + v * Geo<N, BPW>::IMG_BYTES + lane * C + r];
+            if (L::ONE) { // one image, in the agent's view; the stored frame is the mover's
+                const bool flip = c != (int)((regs[3 * 64 + lane] >> 3) & 1u);
+                u32 x = sblk[L::IMG + lane * C + (flip ? L::transpose(r) : r)];
+                board[(size_t)env * C + r] = (signed char)((flip && x) ? x ^ 0xFEu : x);
+            } else {
+                const int v = (L::TWOV && c) ? 1 : 0;
+                board[(size_t)env * C + r] = (signed char)sblk[L::IMG + v * Geo<N, BPW>::IMG_BYTES + lane * C + r];
+            }
         }
     } else if (cur) {
         cur[env] = (unsigned char)c;
     }
 }
 
-template <int N, int ENC, int BPW>
+template <int N, int ENC, int BPW, int VIEWS>
 __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsigned char *agents)
 {
-    using L = Lpb<N, ENC, BPW>;
+    using L = Lpb<N, ENC, BPW, VIEWS>;
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
-        const unsigned char *sblk = fast + (size_t)(i / BPW) * FastState<N, ENC, BPW>::BLOCK_BYTES;
+        const unsigned char *sblk = fast + (size_t)(i / BPW) * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
         const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
         for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i % BPW)];
         if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i % BPW)] >> 3) & 1u);
@@ -836,14 +890,24 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
 // ---- launchers of this translation unit ----
 #define HV_LPB_SIZES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14)
 
-template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
+// enc B: two-sided handles keep both views, self-play handles one image per board (hexvec_lpb.h header)
+template <int N, int ENC, int MODE, int VIEWS> static hipError_t lpb_launch2(const KArgs &a, hipStream_t st)
 {
     const int blocks = (a.E + HV_BPW - 1) / HV_BPW;
     // the helper wave pays off where compute dominates (self-play rollout: measured +10 %); the
     // two-sided rollout is store-bound and loses 15 % to the handshake, the others do not care
     constexpr int HELPER = (HV_HELPER && MODE == M_ROLLOUT1) ? 1 : 0;
-    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
     return hipGetLastError();
+}
+template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
+{
+    if (ENC == 0) return lpb_launch2<N, ENC, MODE, 1>(a, st);
+    const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
+    // (the self-play rollout exists on self-play handles only, the two-sided one on two-sided handles)
+    if (MODE == M_ROLLOUT1) return two ? hipErrorInvalidValue : lpb_launch2<N, ENC, MODE, 1>(a, st);
+    if (MODE == M_ROLLOUT2) return two ? lpb_launch2<N, ENC, MODE, 2>(a, st) : hipErrorInvalidValue;
+    return two ? lpb_launch2<N, ENC, MODE, 2>(a, st) : lpb_launch2<N, ENC, MODE, 1>(a, st);
 }
 template <int N, int ENC> static hipError_t lpb_launch_mode(int mode, const KArgs &a, hipStream_t st)
 {
@@ -865,26 +929,29 @@ hipError_t HV_LPB_NAME(launch)(int N, int enc, int mode, const KArgs &a, hipStre
     default: return hipErrorInvalidValue;
     }
 }
-size_t HV_LPB_NAME(block_bytes)(int N, int enc)
+size_t HV_LPB_NAME(block_bytes)(int N, int enc, int two)
 {
     switch (N) {
-#define HV_CASE(n) \
-    case n: return enc ? lpb::FastState<n, 1, HV_BPW>::BLOCK_BYTES : lpb::FastState<n, 0, HV_BPW>::BLOCK_BYTES;
+#define HV_CASE(n)                                                                              \
+    case n:                                                                                     \
+        return !enc ? lpb::FastState<n, 0, HV_BPW, 1>::BLOCK_BYTES                              \
+                    : two ? lpb::FastState<n, 1, HV_BPW, 2>::BLOCK_BYTES : lpb::FastState<n, 1, HV_BPW, 1>::BLOCK_BYTES;
         HV_LPB_SIZES(HV_CASE)
 #undef HV_CASE
     default: return 0;
     }
 }
-hipError_t HV_LPB_NAME(get_state)(const unsigned char *fast, int N, int enc, int E, signed char *board,
+hipError_t HV_LPB_NAME(get_state)(const unsigned char *fast, int N, int enc, int two, int E, signed char *board,
                                   unsigned char *cur, hipStream_t st)
 {
     const long long total = (long long)E * (N * N + 1);
     const dim3 g((unsigned)((total + 255) / 256)), b(256);
     switch (N) {
-#define HV_CASE(n)                                                                                          \
-    case n:                                                                                                 \
-        if (enc) hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 1, HV_BPW>), g, b, 0, st, fast, E, board, cur); \
-        else hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 0, HV_BPW>), g, b, 0, st, fast, E, board, cur);     \
+#define HV_CASE(n)                                                                                                  \
+    case n:                                                                                                         \
+        if (!enc) hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 0, HV_BPW, 1>), g, b, 0, st, fast, E, board, cur);     \
+        else if (two) hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 1, HV_BPW, 2>), g, b, 0, st, fast, E, board, cur); \
+        else hipLaunchKernelGGL((lpb::k_lpb_get_state<n, 1, HV_BPW, 1>), g, b, 0, st, fast, E, board, cur);          \
         break;
         HV_LPB_SIZES(HV_CASE)
 #undef HV_CASE
@@ -892,15 +959,17 @@ hipError_t HV_LPB_NAME(get_state)(const unsigned char *fast, int N, int enc, int
     }
     return hipGetLastError();
 }
-hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int E, double *out4,
+// out4 must have been zeroed on the same stream (the blocks add their partial sums)
+hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int two, int E, double *out4,
                               unsigned char *agents, hipStream_t st)
 {
-    const dim3 grid((E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024);
+    const dim3 grid((E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024), b(256);
     switch (N) {
-#define HV_CASE(n)                                                                                                  \
-    case n:                                                                                                         \
-        if (enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW>), grid, dim3(256), 0, st, fast, E, out4, agents); \
-        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0, HV_BPW>), grid, dim3(256), 0, st, fast, E, out4, agents);     \
+#define HV_CASE(n)                                                                                                     \
+    case n:                                                                                                            \
+        if (!enc) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 0, HV_BPW, 1>), grid, b, 0, st, fast, E, out4, agents);       \
+        else if (two) hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW, 2>), grid, b, 0, st, fast, E, out4, agents);   \
+        else hipLaunchKernelGGL((lpb::k_lpb_stats<n, 1, HV_BPW, 1>), grid, b, 0, st, fast, E, out4, agents);            \
         break;
         HV_LPB_SIZES(HV_CASE)
 #undef HV_CASE
