@@ -22,7 +22,7 @@ F_TWO_SIDED = 0x20
 F_EXACT_LABELS = 0x40
 F_ROLLOUT_LAYOUT = 0x80
 
-MIN_BOARD, MAX_BOARD = 2, 14
+MIN_BOARD, MAX_BOARD, MAX_BOARD_LABELS = 2, 19, 14
 
 SYMBOLS = [
     "hexvec_create", "hexvec_destroy", "hexvec_reset", "hexvec_step", "hexvec_step_agent",

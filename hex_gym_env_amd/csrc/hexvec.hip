@@ -112,7 +112,8 @@ static const char *qpb_kname(int mode)
 }
 // the translation unit that holds board size N
 #define HV_QPB_CALL(N, fn, ...) \
-    ((N) <= 8 ? hv::qpb_s_##fn(__VA_ARGS__) : (N) <= 11 ? hv::qpb_m_##fn(__VA_ARGS__) : hv::qpb_l_##fn(__VA_ARGS__))
+    ((N) <= 8 ? hv::qpb_s_##fn(__VA_ARGS__) : (N) <= 11 ? hv::qpb_m_##fn(__VA_ARGS__)   \
+     : (N) <= 14 ? hv::qpb_l_##fn(__VA_ARGS__) : hv::qpb_x_##fn(__VA_ARGS__))
 
 static int run(hexvec *h, int mode, const KArgs &a, void *stream)
 {
@@ -139,7 +140,12 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     if (!out) return fail(HEXVEC_E_ARG, "%s", "out is NULL");
     *out = nullptr;
     if (board_size < HEXVEC_MIN_BOARD || board_size > HEXVEC_MAX_BOARD)
-        return fail(HEXVEC_E_ARG, "%s", "board_size must be in 2..14");
+        return fail(HEXVEC_E_ARG, "%s", "board_size must be in 2..19");
+    if (board_size > HEXVEC_MAX_BOARD_LABELS &&
+        (flags & (HEXVEC_F_NO_AUTO_RESET | HEXVEC_F_EXACT_LABELS | HEXVEC_F_ROLLOUT_LAYOUT)))
+        return fail(HEXVEC_E_ARG, "%s",
+                    "board_size 15..19 runs on the default (bitboard) layout of auto-reset handles only: the literal "
+                    "engine and the rollout layout keep one-byte labels / connectivity entries (2..14)");
     if (num_envs < 1) return fail(HEXVEC_E_ARG, "%s", "num_envs must be >= 1");
     if (!(flags & HEXVEC_F_ENC_B) && (flags & (HEXVEC_F_AGENT_WHITE | HEXVEC_F_AGENT_RANDOM)))
         return fail(HEXVEC_E_ARG, "%s",

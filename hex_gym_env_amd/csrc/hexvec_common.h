@@ -100,6 +100,7 @@ hipError_t lpb64_stats(const unsigned char *fast, int N, int enc, int two, int E
 HV_QPB_DECL(s)
 HV_QPB_DECL(m)
 HV_QPB_DECL(l)
+HV_QPB_DECL(x)
 #undef HV_QPB_DECL
 // geometry of that family (must match qpb::Geo<N>)
 inline int qpb_lanes(int N)

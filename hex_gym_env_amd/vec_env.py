@@ -30,6 +30,9 @@ class HexVecEnv:
                  env_offset=0, exact_labels=False, rollout_layout=False):
         if not (_lib.MIN_BOARD <= board_size <= _lib.MAX_BOARD):
             raise ValueError(f"board_size must be in {_lib.MIN_BOARD}..{_lib.MAX_BOARD}")
+        if board_size > _lib.MAX_BOARD_LABELS and (not auto_reset or exact_labels or rollout_layout is True):
+            raise ValueError(f"board_size > {_lib.MAX_BOARD_LABELS} runs on the default layout of auto-reset "
+                             "handles only (include/hexvec.h)")
         if encoding not in ("A", "B"):
             raise ValueError("encoding must be 'A' (hex-v0 / HexGame.py) or 'B' (HexSingleGame.py)")
         if not torch.cuda.is_available():
@@ -66,7 +69,7 @@ class HexVecEnv:
             # The lane-per-board layout runs one playing wavefront per 64 boards and needs about one per
             # SIMD (1 024 on MI355X) to win; below ~3/4 of that the bitboard kernels (4x the wavefronts at
             # 9x9..11x11) fill the chip better (measured: DESIGN.md, occupancy table).
-            rollout_layout = (num_envs + 63) // 64 >= 768
+            rollout_layout = (num_envs + 63) // 64 >= 768 and board_size <= _lib.MAX_BOARD_LABELS
         if rollout_layout:      # state laid out for rollout_selfplay / rollout_random (include/hexvec.h)
             flags |= _lib.F_ROLLOUT_LAYOUT
         # auto-reset handles run on the bitboard / lane-per-board kernels (include/hexvec.h)

@@ -22,8 +22,11 @@
  *     encoding B: -1 / 0 / +1 in the perspective of the player to move);
  *     legal uint8 [E, N*N] (1 = empty); actions int32 [E]; reward float32 [E];
  *     done uint8 [E]; winner/ret int8 [E]: -1 None, 0 BLACK, 1 WHITE, 3 illegal.
- *   - board_size 2..14 (connectivity entries / labels are one byte; a padded label
- *     plane is one dword per lane); larger boards are rejected with HEXVEC_E_ARG.
+ *   - board_size 2..19 on the default layout of auto-reset handles (bitboards: up to 16 lanes x 32
+ *     cells per board); 2..14 on NO_AUTO_RESET / EXACT_LABELS / ROLLOUT_LAYOUT handles (labels and
+ *     union-find entries are one byte; a padded label plane is one dword per lane); anything else is
+ *     rejected with HEXVEC_E_ARG.  (The reference sets no limit, HexSingleGame.py:163-172; its scripts
+ *     stop at 11x11.)
  *
  * Three kernel families serve a handle, chosen at create time:
  *   - auto-reset handles (the default) run on the bitboard kernels: 1 / 2 / 4 / 8
@@ -60,7 +63,8 @@ extern "C" {
 typedef struct hexvec hexvec_t;
 
 #define HEXVEC_MIN_BOARD 2
-#define HEXVEC_MAX_BOARD 14
+#define HEXVEC_MAX_BOARD 19        /* default (bitboard) layout of auto-reset handles              */
+#define HEXVEC_MAX_BOARD_LABELS 14 /* NO_AUTO_RESET / EXACT_LABELS / ROLLOUT_LAYOUT handles         */
 
 /* error codes */
 #define HEXVEC_OK 0

@@ -452,7 +452,10 @@ def test_selfplay_full_size_step_properties(hx):
 
 def test_errors_are_loud(hx):
     with pytest.raises(ValueError):
-        hx.HexVecEnv(15, 4)
+        hx.HexVecEnv(20, 4)
+    for kw in (dict(auto_reset=False), dict(exact_labels=True), dict(rollout_layout=True)):
+        with pytest.raises(ValueError):
+            hx.HexVecEnv(15, 4, **kw)            # labels / union-find entries are one byte: 2..14
     with pytest.raises(NotImplementedError):
         hx.HexVecEnv(5, 4, encoding="A", agent_player_num=1)
     e = hx.HexVecEnv(5, 4, encoding="B")
@@ -484,6 +487,33 @@ def test_lane_per_board_odd_env_counts(hx, n, E, enc, lay):
         assert np.array_equal(_np(rew), orw), k
         assert np.array_equal(_np(done), od), k
     _same_state(g2, o2)
+
+
+@pytest.mark.parametrize("n", [15, 16, 17, 19])
+def test_large_boards_on_the_bitboard_layout_vs_oracle(hx, n):
+    """15x15..19x19 (8 or 16 lanes per board): self-play steps with mixed RNG / external actions, both
+    encodings, then a two-sided rollout -- all rows against the oracle"""
+    E, K = 96, 3 * n * n // 2
+    rng = np.random.default_rng(n)
+    for enc, first in (("B", 0), ("A", n % 2)):
+        g, o = _pair(hx, n, E, enc, agent=None, first=first, seed=77 + n)
+        for k in range(K):
+            a = rng.integers(0, n * n, size=E).astype(np.int32) if k % 6 == 5 else None
+            obs, rew, done, legal, win = g.step(a)
+            oo, ol, orw, od, ow = o.step(a)
+            assert np.array_equal(_np(obs).reshape(E, -1), oo), (enc, k)
+            assert np.array_equal(_np(legal), ol), (enc, k)
+            assert np.array_equal(_np(rew), orw) and np.array_equal(_np(done), od), (enc, k)
+            assert np.array_equal(_np(win), ow), (enc, k)
+        assert o.episode_stats()[2] > E // 2
+        _same_state(g, o)
+    g, o = _pair(hx, n, 40, "B", two_sided=True, seed=5 + n)
+    T = n * n + 9
+    out = g.rollout_random(T)
+    oobs, olegal, oact, orew, odone = o.rollout(T)
+    for k, ref in (("obs", oobs), ("legal", olegal), ("actions", oact), ("reward", orew), ("done", odone)):
+        assert np.array_equal(_np(out[k]), ref), k
+    _same_state(g, o)
 
 
 @pytest.mark.parametrize("n", list(range(4, 15)))

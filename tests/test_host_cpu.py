@@ -48,7 +48,10 @@ def test_create_rejects_bad_arguments_before_touching_the_gpu():
     from hex_gym_env_amd import _lib
     L = _lib.lib()
     h = C.c_void_p()
-    assert L.hexvec_create(C.byref(h), 15, 4, 0, C.c_uint64(0), 1, 0) == -1
+    assert L.hexvec_create(C.byref(h), 20, 4, 0, C.c_uint64(0), 1, 0) == -1
+    assert L.hexvec_create(C.byref(h), 15, 4, 0, C.c_uint64(0), 1 | 0x8, 0) == -1    # no auto reset: 2..14
+    assert L.hexvec_create(C.byref(h), 15, 4, 0, C.c_uint64(0), 1 | 0x40, 0) == -1   # exact labels: 2..14
+    assert L.hexvec_create(C.byref(h), 15, 4, 0, C.c_uint64(0), 1 | 0x80, 0) == -1   # rollout layout: 2..14
     assert L.hexvec_create(C.byref(h), 1, 4, 0, C.c_uint64(0), 1, 0) == -1
     assert L.hexvec_create(C.byref(h), 5, 0, 0, C.c_uint64(0), 1, 0) == -1
     assert L.hexvec_create(C.byref(h), 5, 4, 0, C.c_uint64(0), 0x2, 0) == -1   # enc A + WHITE agent
