@@ -51,6 +51,28 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def allreduce_gradients(params, average=True):
+    """Data-parallel PPO (optional): every rank collects rollouts from its own env shard
+    and back-propagates its own minibatch; before optimizer.step() the gradients are summed over the
+    ranks.  The SB3 default policy of the reference's scripts (obs -> 64 -> 64 -> N*N logits + value,
+    ~41 k parameters = 164 KB in fp32 at 11x11) is far below one RCCL bucket, so ALL gradients travel as
+    ONE flattened all-reduce (xGMI is point-to-point: one latency-bound ring pass instead of one per
+    tensor), then are copied back in place.  A no-op without a process group.  Returns the bytes reduced."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return flat.numel() * flat.element_size()
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

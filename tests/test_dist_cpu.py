@@ -73,3 +73,48 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hex_gym_env_amd.dist import allreduce_gradients
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy
+    torch.manual_seed(0)                                   # same initial weights on every rank
+    pol = MlpActorPolicy(25)
+    x = torch.randn(64, 25, generator=torch.Generator().manual_seed(100 + rank))   # this rank's minibatch
+    loss = pol.action_net(pol.policy_net(x)).logsumexp(1).mean()
+    loss.backward()
+    nbytes = allreduce_gradients(pol.parameters())
+    q.put((rank, nbytes, [p.grad.clone().numpy() for p in pol.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_the_full_batch():
+    """data-parallel PPO step (optional row N2): the averaged shard gradients equal the gradient of
+    the mean loss over both minibatches, moved as one flattened all-reduce"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy
+    torch.manual_seed(0)
+    pol = MlpActorPolicy(25)
+    xs = [torch.randn(64, 25, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    loss = sum(pol.action_net(pol.policy_net(x)).logsumexp(1).mean() for x in xs) / world
+    loss.backward()
+    nparams = sum(p.numel() for p in pol.parameters())
+    for rank, nbytes, grads in res:
+        assert nbytes == 4 * nparams
+        for g, p in zip(grads, pol.parameters()):
+            assert np.allclose(g, p.grad.numpy(), atol=1e-6)
