@@ -63,19 +63,17 @@ def sample_masked(logits, legal, generator=None, bad_rows=None):
     trick: argmax(logits + G).  Same distribution as multinomial(softmax(masked logits)) but without
     torch.multinomial's device-side assertion, so it can be captured in a hipGraph.
 
-    A DEGENERATE row -- no legal cell, or a non-finite logit on a legal cell -- cannot be sampled; it
-    yields action 0 (an illegal ply, which ends the episode with reward 0) and is COUNTED in `bad_rows`
+    A DEGENERATE row -- no legal cell, or a NaN logit on a legal cell -- cannot be sampled; it yields
+    an arbitrary action (an illegal ply ends the episode with reward 0) and is COUNTED in `bad_rows`
     (int64 scalar on the device, incremented in place) so that it never passes silently: the policies
     below own such a counter and VecSelfPlayEnv.degenerate_rows() reads them."""
-    ok = legal != 0
-    lf = logits.float()
-    if bad_rows is not None:
-        bad = ~ok.any(1) | (ok & ~torch.isfinite(lf)).any(1)
-        bad_rows.add_(bad.sum())
     u = torch.rand(logits.shape, generator=generator, device=logits.device, dtype=torch.float32)
     g = -torch.log(-torch.log(u.clamp_(1e-20, 1.0 - 1e-7)))
-    z = torch.where(ok, lf + g, torch.full_like(g, float("-inf")))
-    return z.argmax(1)
+    z = torch.where(legal != 0, logits.float() + g, torch.full_like(g, float("-inf")))
+    best, idx = z.max(1)            # one kernel for value and index
+    if bad_rows is not None:        # a row without a legal cell peaks at -inf, one with a NaN logit at NaN
+        bad_rows.add_((~(best > float("-inf"))).sum())
+    return idx
 
 
 class _CountsBadRows:
