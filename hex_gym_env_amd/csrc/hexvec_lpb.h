@@ -48,6 +48,45 @@
 #pragma once
 #include "hexvec_common.h"
 
+// Diagnostic build (-DHV_STAMPS, tools/stamp_rollout.py): s_memtime stamps around the sections of a
+// self-play step (and inside place()), summed per playing wavefront into a buffer of their own.  No
+// stamp exists in the product build.
+#ifdef HV_STAMPS
+__device__ unsigned long long g_stamps[4096][12];
+struct StampBox {
+    unsigned long long acc[4], prev;
+};
+#define HV_STAMP_INIT()                                                                               \
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(); \
+    g_box.acc[0] = g_box.acc[1] = g_box.acc[2] = g_box.acc[3] = 0
+#define HV_MARK(k)                                                      \
+    do {                                                                \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        st_acc[k] += st_now - st_prev;                                  \
+        st_prev = st_now;                                               \
+    } while (0)
+#define HV_PMARK0(box) (box).prev = __builtin_amdgcn_s_memtime()
+#define HV_PMARK(box, k)                                                \
+    do {                                                                \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        (box).acc[k] += st_now - (box).prev;                            \
+        (box).prev = st_now;                                            \
+    } while (0)
+#define HV_STAMP_FLUSH(blk)                                                                                  \
+    do {                                                                                                     \
+        if (lane == 0 && (blk) < 4096)                                                                       \
+            for (int k_ = 0; k_ < 12; ++k_) g_stamps[blk][k_] = k_ < 8 ? st_acc[k_] : g_box.acc[k_ - 8];     \
+    } while (0)
+#else
+struct StampBox {
+};
+#define HV_STAMP_INIT() do { } while (0)
+#define HV_MARK(k) do { } while (0)
+#define HV_PMARK0(box) do { } while (0)
+#define HV_PMARK(box, k) do { } while (0)
+#define HV_STAMP_FLUSH(blk) do { } while (0)
+#endif
+
 namespace hv {
 namespace lpb {
 
@@ -199,8 +238,9 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
     // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
     // true iff p now connects its two edges (HexGame.py:98-105 via connectivity).
     static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int y, int x,
-                                                 int lane)
+                                                 int lane, StampBox &box)
     { // (y, x): coordinates of the stone in p's own frame
+        HV_PMARK0(box);
         // union-find in p's own frame: issue the six neighbour reads first, their LDS latency is
         // covered by the bitboard / image updates below
         unsigned char *uf = lds + (p * BPW + lane) * PS;
@@ -224,6 +264,7 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         clear_bit(s.E1, idx1);
         s.n_empty -= 1;
         put_stone(lds, s, idx0, idx1, p, lane);
+        HV_PMARK(box, 0); // neighbour reads issued, bitboards / image updated
         // follow child pointers to the roots (all six chains of all lanes together)
         for (;;) {
             bool any = false;
@@ -240,6 +281,7 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
                 e[i] = uf[ix[i]];
             }
         }
+        HV_PMARK(box, 1); // chase
         // union by rank: everything hangs under the highest-rank root.  After the chase every e[i]
         // is 0 (no stone) or a root byte 0xE0|rank<<2|flags; key = (rank+1)<<8 | root index.
         u32 fl = (y == 0 ? 1u : 0u) | (y == N - 1 ? 2u : 0u);
@@ -263,6 +305,7 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         const u32 root_byte = 0xE0u | (rank << 2) | fl;
         uf[a] = has ? (unsigned char)(best_ix + 1) : (unsigned char)root_byte;
         uf[best_ix] = (unsigned char)root_byte; // TRASH when the stone has no neighbour of its colour
+        HV_PMARK(box, 2); // union
         return fl == 3u;
     }
 
@@ -497,6 +540,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     // helper (barrier 1); emit_release() is the second barrier ("snapshot taken") and is called as
     // late as possible -- right before wave 0 next touches the images -- so that wave 0 draws its
     // next action while the helper reads LDS.
+    StampBox g_box; // (diagnostic build only)
     u64 agent1 = 0ull; // one-image boards: bit d = board d's image is kept in the WHITE-to-move view
     bool release_owed = false;
     auto emit_release = [&]() {
@@ -570,7 +614,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         if (check && (!inb || !L::test_bit(s.E0, idx0))) return 3;
         const int p = s.cur;
         const bool same = p == fr; // the plane of colour p is indexed in p's own frame
-        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane) || ((s.prewon >> p) & 1);
+        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane, g_box) || ((s.prewon >> p) & 1);
         int ret = -1;
         if (win) {
             s.done = 1;
@@ -655,7 +699,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                     const int p = B ? (v == -1 ? 0 : (v == 1 ? 1 : -1)) : (v == 0 ? 0 : (v == 1 ? 1 : -1));
                     if (p >= 0) {
                         const int y = c / N, x = c - y * N;
-                        if (L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane)) s.prewon |= 1 << p;
+                        if (L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane, g_box)) s.prewon |= 1 << p;
                     }
                 }
                 if (opens) s.pend = 2; // the opponent still owes its opening (split step)
@@ -725,8 +769,10 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             if (live && a.pending) a.pending[o] = (unsigned char)s.pend;
             do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + (size_t)e0 * C : nullptr,
                     a.legal ? a.legal + (size_t)e0 * C : nullptr);
-        } else
+        } else {
+        HV_STAMP_INIT();
         for (int t = 0; t < a.T; ++t) {
+            HV_MARK(7);
             const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
             const size_t o = ob + (size_t)lane;
             signed char *tobs_row = a.tobs ? a.tobs + ob * C : nullptr;
@@ -738,7 +784,9 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             bool reply = false; // this lane still owes the opponent's reply
             // B: the mover's frame.  Drawn before the helper's release barrier: registers only.
             const int act = ext_a ? (live ? a.actions[o] : 0) : L::rng_action(s, B ? s.cur : 0);
+            HV_MARK(0); // agent action (rng + k-th empty)
             emit_release();
+            HV_MARK(1); // wait for the helper's snapshot
             if (live) {
                 if (two) {
                     const int mover = s.cur;
@@ -776,7 +824,9 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 }
             }
             const bool dn1 = live && !reply && s.done;
+            HV_MARK(2); // agent ply
             handle_done(dn1, won, tobs_row);
+            HV_MARK(3); // finished boards
             // ---- slot 2: the opponent's reply, or its opening on the boards just reset
             if (selfplay) {
                 const bool open2 = dn1 && opens;
@@ -795,6 +845,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                     }
                 }
                 const bool dn2 = reply && s.done;
+                HV_MARK(4); // opponent action + ply
                 handle_done(dn2, won, tobs_row);
                 // ---- slot 3: openings of the boards that ended on the reply
                 if (dn2 && opens) opening_on_empty();
@@ -805,9 +856,13 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 if (a.winner) a.winner[o] = (signed char)f_winner;
                 if (a.actions_out) a.actions_out[o] = act;
             }
+            HV_MARK(5); // finished boards 2, slot 3, scalar outputs
             if (MODE != M_ROLLOUT2)
                 do_emit(B ? __ballot(s.cur != 0) : 0ull, a.obs ? a.obs + ob * C : nullptr,
                     a.legal ? a.legal + ob * C : nullptr);
+            HV_MARK(6); // publish the emission (barrier 1)
+        }
+        HV_STAMP_FLUSH(blk);
         }
     }
 
@@ -977,5 +1032,12 @@ hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int two
     }
     return hipGetLastError();
 }
+
+#ifdef HV_STAMPS
+extern "C" int hexvec_debug_stamps(unsigned long long *host_dst, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * 12 * sizeof(unsigned long long));
+}
+#endif
 
 } // namespace hv
