@@ -58,7 +58,9 @@ struct StampBox {
 };
 #define HV_STAMP_INIT()                                                                               \
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(); \
-    g_box.acc[0] = g_box.acc[1] = g_box.acc[2] = g_box.acc[3] = 0
+    g_box.acc[0] = g_box.acc[1] = g_box.acc[2] = 0;                                                   \
+    g_box.acc[3] = __builtin_amdgcn_s_memrealtime() /* workgroup start, 100 MHz */;                   \
+    st_acc[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */
 #define HV_MARK(k)                                                      \
     do {                                                                \
         const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
@@ -772,7 +774,6 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         } else {
         HV_STAMP_INIT();
         for (int t = 0; t < a.T; ++t) {
-            HV_MARK(7);
             const size_t ob = (size_t)t * E + (size_t)e0; // first board of this block in row t
             const size_t o = ob + (size_t)lane;
             signed char *tobs_row = a.tobs ? a.tobs + ob * C : nullptr;

@@ -24,12 +24,18 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+LAYOUTS = pytest.mark.parametrize("lay", [False, True], ids=["bitboard", "lane-per-board"])
+
+
 @pytest.mark.parametrize("n,enc,agent,first", [(5, "B", None, 0), (11, "B", 1, 0), (7, "B", 0, 0),
-                                               (5, "A", None, 1), (9, "A", None, 0)])
-def test_split_step_equals_fused_step(hx, n, enc, agent, first):
-    """step_agent + step_opponent rounds with library-drawn actions == the oracle's whole step"""
+                                               (5, "A", None, 1), (9, "A", None, 0), (13, "B", None, 0)])
+@LAYOUTS
+def test_split_step_equals_fused_step(hx, n, enc, agent, first, lay):
+    """step_agent + step_opponent rounds with library-drawn actions == the oracle's whole step
+    (on the lane-per-board layout the opponent's view is read out of the agent's image as the negated
+    transpose: hexvec_lpb.h emit_gather)"""
     E, K = 192, 5 * n
-    g = hx.HexVecEnv(n, E, encoding=enc, agent_player_num=agent, first_player=first, seed=21)
+    g = hx.HexVecEnv(n, E, encoding=enc, agent_player_num=agent, first_player=first, seed=21, rollout_layout=lay)
     f = ho.F_ENC_B | (ho.F_AGENT_RANDOM if agent is None else (ho.F_AGENT_WHITE if agent else 0)) \
         if enc == "B" else (ho.F_FIRST_WHITE if first else 0)
     o = ho.OracleVec(n, E, seed=21, flags=f)
@@ -56,11 +62,12 @@ def test_split_step_equals_fused_step(hx, n, enc, agent, first):
         hx.HexVecEnv(n, 8, encoding=enc, two_sided=True).step_agent()
 
 
-def test_opponent_sees_its_own_view_and_its_reply_lands(hx):
+@LAYOUTS
+def test_opponent_sees_its_own_view_and_its_reply_lands(hx, lay):
     """a deterministic 'first legal cell' opponent: the reply must be the first empty cell of the
     opponent's view (= -board^T), HexSingleGame.py:265-271 + SelfplayWrapper.py:161"""
     n, E = 6, 256
-    g = hx.HexVecEnv(n, E, encoding="B", agent_player_num=0, seed=5)
+    g = hx.HexVecEnv(n, E, encoding="B", agent_player_num=0, seed=5, rollout_layout=lay)
     obs, legal = g.reset()
     rng = np.random.default_rng(0)
     for k in range(12):
@@ -155,15 +162,16 @@ def test_reference_trained_actor_beats_random_play(hx):
     assert trained_agent_winrate > 0.75, trained_agent_winrate
 
 
-@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("exact", [False, True, "lpb"])
 def test_state_dict_roundtrip_and_render(hx, exact):
     n, E = 7, 200
-    a = hx.HexVecEnv(n, E, encoding="B", seed=2, exact_labels=exact)
+    kw = dict(rollout_layout=True) if exact == "lpb" else dict(exact_labels=exact)
+    a = hx.HexVecEnv(n, E, encoding="B", seed=2, **kw)
     for _ in range(9):
         a.step()
     sd = a.state_dict()
     ref = [tuple(_np(x).copy() for x in a.step()) for _ in range(15)]
-    b = hx.HexVecEnv(n, E, encoding="B", seed=2, exact_labels=exact)
+    b = hx.HexVecEnv(n, E, encoding="B", seed=2, **kw)
     b.load_state_dict(sd)
     for r in ref:
         out = b.step()
@@ -198,8 +206,9 @@ def test_device_board_sampler_matches_reference_distribution():
 
 
 @pytest.mark.parametrize("n,enc", [(5, "B"), (11, "B"), (7, "A"), (14, "B")])
-def test_set_boards_matches_exact_engine(hx, n, enc):
-    """start positions on the lane-per-board state == constructor replay on the exact engine
+@pytest.mark.parametrize("lay", [False, True], ids=["bitboard", "lane-per-board"])
+def test_set_boards_matches_exact_engine(hx, n, enc, lay):
+    """start positions on the throughput layouts == constructor replay on the exact engine
     (which tests/test_gpu_mirror.py pins to the reference's regions)"""
     from hex_gym_env_amd.vec_selfplay import sample_boards
     E = 192
@@ -207,7 +216,7 @@ def test_set_boards_matches_exact_engine(hx, n, enc):
     boards = sample_boards(n, E, g, "cuda")
     if enc == "A":
         boards = torch.where(boards == -1, 0, torch.where(boards == 1, 1, 2)).to(torch.int8)
-    fast = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=1)
+    fast = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=1, rollout_layout=lay)
     exact = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=1, exact_labels=True)
     obs, legal, pend = fast.set_boards(boards)
     exact.set_state(boards.reshape(E, -1))
