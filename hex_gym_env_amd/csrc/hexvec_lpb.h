@@ -248,57 +248,72 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         unsigned char *uf = lds + (p * BPW + lane) * PS;
         const int a = p ? idx1 : idx0;
         const bool up = y > 0, dn = y < N - 1, lf = x > 0, rt = x < N - 1;
+        // the six neighbours in RING order (each is adjacent to the next, the last to the first):
+        // up, up-right, right, down, down-left, left
         int nb[6];
         nb[0] = up ? a - N : G::DUMMY;
         nb[1] = (up && rt) ? a - N + 1 : G::DUMMY;
-        nb[2] = lf ? a - 1 : G::DUMMY;
-        nb[3] = rt ? a + 1 : G::DUMMY;
+        nb[2] = rt ? a + 1 : G::DUMMY;
+        nb[3] = dn ? a + N : G::DUMMY;
         nb[4] = (dn && lf) ? a + N - 1 : G::DUMMY;
-        nb[5] = dn ? a + N : G::DUMMY;
-        int ix[6];
-        u32 e[6];
+        nb[5] = lf ? a - 1 : G::DUMMY;
+        u32 e6[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            ix[i] = nb[i];
-            e[i] = uf[ix[i]];
-        }
+        for (int i = 0; i < 6; ++i) e6[i] = uf[nb[i]];
         clear_bit(s.E0, idx0);
         clear_bit(s.E1, idx1);
         s.n_empty -= 1;
         put_stone(lds, s, idx0, idx1, p, lane);
         HV_PMARK(box, 0); // neighbour reads issued, bitboards / image updated
-        // follow child pointers to the roots (all six chains of all lanes together)
+        // Stones of p on consecutive ring cells touch each other, so they already share a root: ONE cell
+        // per run of p-stones around the ring represents its group, and there are at most three runs.
+        // Two run starts are never ring-adjacent, so each ring pair (0,1) (2,3) (4,5) holds at most one:
+        // three chains to chase and three roots to unite instead of six.
+        bool own[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) own[i] = e6[i] != 0u;
+        const bool ring_full = own[0] && own[1] && own[2] && own[3] && own[4] && own[5]; // one run, no start
+        int ix[3];
+        u32 e[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool s0 = (own[2 * k] && !own[(2 * k + 5) % 6]) || (k == 0 && ring_full);
+            const bool s1 = own[2 * k + 1] && !own[2 * k];
+            ix[k] = s1 ? nb[2 * k + 1] : (s0 ? nb[2 * k] : G::DUMMY);
+            e[k] = s1 ? e6[2 * k + 1] : (s0 ? e6[2 * k] : 0u);
+        }
+        // follow child pointers to the roots (all chains of all lanes together)
         for (;;) {
             bool any = false;
-            bool ch[6];
+            bool ch[3];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 ch[i] = (e[i] - 1u) < 0xDFu; // 1..0xDF: child
                 any = any || ch[i];
             }
             if (!__ballot(any)) break;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 ix[i] = ch[i] ? (int)e[i] - 1 : ix[i];
                 e[i] = uf[ix[i]];
             }
         }
         HV_PMARK(box, 1); // chase
         // union by rank: everything hangs under the highest-rank root.  After the chase every e[i]
-        // is 0 (no stone) or a root byte 0xE0|rank<<2|flags; key = (rank+1)<<8 | root index.
+        // is 0 (no group) or a root byte 0xE0|rank<<2|flags; key = (rank+1)<<8 | root index.
         u32 fl = (y == 0 ? 1u : 0u) | (y == N - 1 ? 2u : 0u);
-        u32 key[6];
+        u32 key[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 3; ++i) {
             fl |= e[i] & 3u;
             key[i] = e[i] != 0u ? ((((e[i] >> 2) & 7u) + 1u) << 8) | (u32)ix[i] : 0u;
         }
-        const u32 best = max(max(max(key[0], key[1]), max(key[2], key[3])), max(key[4], key[5]));
+        const u32 best = max(max(key[0], key[1]), key[2]);
         const bool has = best != 0u;
         const int best_ix = has ? (int)(best & 0xffu) : G::TRASH;
         u32 second = 0u; // highest key among the OTHER roots
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 3; ++i) {
             const bool other = key[i] != 0u && (key[i] & 0xffu) != (best & 0xffu);
             second = max(second, other ? key[i] : 0u);
             uf[other ? ix[i] : G::TRASH] = (unsigned char)(best_ix + 1);
