@@ -519,8 +519,10 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     using LS = typename L::LS;
     constexpr bool B = ENC == 1;
     constexpr int C = G::C, JW = G::JW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES + (HELPER ? 16 : 0)];
+    // (helper kernels: + the view mask of the emission and one word of scalar outputs per board)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[L::LDS_BYTES + (HELPER ? 16 + 256 : 0)];
     u64 *sh_view = reinterpret_cast<u64 *>(lds + L::LDS_BYTES);
+    u32 *sh_scal = reinterpret_cast<u32 *>(lds + L::LDS_BYTES + 16);
 
     const int lane = (int)threadIdx.x & 63;
     const int wave = HELPER ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
@@ -545,9 +547,15 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 const size_t ob = (size_t)t * (size_t)a.E + (size_t)e0;
                 __syncthreads(); // images and view mask of this emission are final
                 const u64 view = *sh_view;
+                const u32 pk = sh_scal[lane]; // this step's action | done << 8 | reward << 16 of board `lane`
                 typename L::Snap sn;
                 L::snapshot(lds, sn, lane);
                 __syncthreads(); // the snapshot is in registers: wave 0 may play on
+                // the step's scalar rows too: a store issued by the playing wave would queue behind these
+                // 16-byte stores in the CU's memory pipeline and stall it (measured: 3-5 % of a step)
+                if (a.reward) a.reward[ob + lane] = (float)(int)(signed char)(pk >> 16);
+                if (a.done) a.done[ob + lane] = (unsigned char)((pk >> 8) & 1u);
+                if (a.actions_out) a.actions_out[ob + lane] = (int)(pk & 0xffu);
                 L::finish_any(sn, view, a.obs ? a.obs + ob * C : nullptr, a.legal ? a.legal + ob * C : nullptr, lane);
             }
         }
@@ -866,7 +874,9 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 // ---- slot 3: openings of the boards that ended on the reply
                 if (dn2 && opens) opening_on_empty();
             }
-            if (live) {
+            if (helper_on && MODE == M_ROLLOUT1) { // the helper stores them with the observation rows
+                sh_scal[lane] = ((u32)act & 0xffu) | ((u32)f_done << 8) | (((u32)rew & 0xffu) << 16);
+            } else if (live) {
                 if (a.reward) a.reward[o] = (float)rew;
                 if (a.done) a.done[o] = (unsigned char)f_done;
                 if (a.winner) a.winner[o] = (signed char)f_winner;
