@@ -132,6 +132,7 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         int prewon; // bit p: colour p was already connected in the start position (set_boards); the
                     // reference notices that on p's next ply, whatever it is (HexGame.py:101-105)
         u32 ctr, key;
+        u32 kc; // key + ctr * 0x9E3779B9, kept in step with ctr (no multiply per draw)
         int ep_ret, ep_len;
         int sr, sl, se, sw;
     };
@@ -167,18 +168,18 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
     // position of the k-th set bit (k < popcount), all per lane
     static __device__ __forceinline__ int kth_set(const u32 (&E)[JW], u32 k)
     {
-        u32 c = 0, word = 0, base = 0;
+        // the word that holds it: running popcounts (the popcount instruction accumulates), then one
+        // select per word boundary -- k < popcount of all words, so the last word needs no test
+        u32 word = E[0], base = 0;
         int widx = 0;
-        bool found = false;
+        u32 c = 0;
 #pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            const u32 pc = (u32)__popc(E[j]);
-            const bool here = !found && k < c + pc;
-            word = here ? E[j] : word;
-            base = here ? c : base;
-            widx = here ? j : widx;
-            found = found || here;
-            c += pc;
+        for (int j = 0; j + 1 < JW; ++j) {
+            c += (u32)__popc(E[j]); // cells in words 0..j
+            const bool past = k >= c;
+            word = past ? E[j + 1] : word;
+            base = past ? c : base;
+            widx = past ? j + 1 : widx;
         }
         k -= base;
         int pos = 0;
@@ -196,7 +197,8 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
 
     static __device__ __forceinline__ u32 draw(LS &s)
     {
-        const u32 r = mix32(s.key + s.ctr * 0x9E3779B9U);
+        const u32 r = mix32(s.kc);
+        s.kc += 0x9E3779B9U;
         s.ctr += 1;
         return r;
     }
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     }
 
     if (L::ONE) agent1 = __ballot(live && s.agent != 0);
+    s.kc = s.key + s.ctr * 0x9E3779B9U;
 
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: FT order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
@@ -849,30 +852,28 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             }
             const bool dn1 = live && !reply && s.done;
             HV_MARK(2); // agent ply
-            handle_done(dn1, won, tobs_row);
-            HV_MARK(3); // finished boards
-            // ---- slot 2: the opponent's reply, or its opening on the boards just reset
-            if (selfplay) {
-                const bool open2 = dn1 && opens;
-                if (reply || open2) {
-                    const bool ext = reply && ext_o;
-                    const int oa = ext ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
-                    const int rb = opponent_ply(oa, ext);
-                    if (reply) {
-                        rew = B ? (s.agent == 0 ? rb : -rb)
-                                : (s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0)));
-                        s.ep_ret += rew;
-                        s.ep_len += 1;
-                        won = s.done && rew > 0;
-                        f_done = s.done;
-                        f_winner = s.winner;
-                    }
+            if (!selfplay) {
+                handle_done(dn1, won, tobs_row);
+            } else {
+                // ---- slot 2: the opponent's reply
+                if (reply) {
+                    const int oa = ext_o ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
+                    const int rb = opponent_ply(oa, ext_o);
+                    rew = B ? (s.agent == 0 ? rb : -rb)
+                            : (s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0)));
+                    s.ep_ret += rew;
+                    s.ep_len += 1;
+                    won = s.done && rew > 0;
+                    f_done = s.done;
+                    f_winner = s.winner;
                 }
-                const bool dn2 = reply && s.done;
                 HV_MARK(4); // opponent action + ply
-                handle_done(dn2, won, tobs_row);
-                // ---- slot 3: openings of the boards that ended on the reply
-                if (dn2 && opens) opening_on_empty();
+                // ---- the boards that ended on either ply: terminal obs, statistics, fresh board (the
+                // ones that ended on the agent's ply were not touched since), then
+                // ---- slot 3: the opponent's opening where it moves first; always drawn by the library
+                const bool dn = dn1 || (reply && s.done);
+                handle_done(dn, won, tobs_row);
+                if (dn && opens) opening_on_empty();
             }
             if (helper_on && MODE == M_ROLLOUT1) { // the helper stores them with the observation rows
                 sh_scal[lane] = ((u32)act & 0xffu) | ((u32)f_done << 8) | (((u32)rew & 0xffu) << 16);
