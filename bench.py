@@ -177,7 +177,11 @@ def main():
     # profile was taken for another configuration or kernel
     traffic, on_chip = None, None
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "bench_pmc_summary.json")))
+        pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+        pfile = os.path.join(pdir, f"bench_T{T}_pmc_summary.json")        # e.g. the 200-steps-per-launch passes
+        if not os.path.exists(pfile):
+            pfile = os.path.join(pdir, "bench_pmc_summary.json")            # the driver's command
+        prof = json.load(open(pfile))
         if (prof["config"] == {"board": N, "envs": E, "steps_per_launch": T}
                 and prof["kernel"].startswith(main_kernel.split("<")[0])):
             c = prof["counters"]["rollout1"]
@@ -190,7 +194,7 @@ def main():
                                                         if c.get("SQ_LDS_IDX_ACTIVE") else None),
                        "valu_insts_per_launch": c["SQ_INSTS_VALU"], "salu_insts_per_launch": c["SQ_INSTS_SALU"],
                        "waves_per_launch": c["SQ_WAVES"],
-                       "source": f"profiles/{PROFILE_ROUND}/bench_pmc_summary.json (rocprofv3 --pmc, same command)"}
+                       "source": f"profiles/{PROFILE_ROUND}/{os.path.basename(pfile)} (rocprofv3 --pmc, same command)"}
     except Exception:
         traffic, on_chip = None, None
 

@@ -102,6 +102,7 @@ template <int N, int ENC> struct Q {
         int pend;   // split step: 0 agent to move, 1 the opponent owes its reply, 2 its opening
         int prewon; // bit p: colour p was already connected in the start position (set_boards)
         u32 ctr, key;
+        u32 kc; // key + ctr * 0x9E3779B9, kept in step with ctr (no multiply per draw)
         int ep_ret, ep_len;
         int sr, sl, se, sw; // episode sums of THIS launch (added to the stats rows at the end)
     };
@@ -189,7 +190,8 @@ template <int N, int ENC> struct Q {
 
     static __device__ __forceinline__ u32 draw(LS &s)
     {
-        const u32 r = mix32(s.key + s.ctr * 0x9E3779B9U);
+        const u32 r = mix32(s.kc);
+        s.kc += 0x9E3779B9U;
         s.ctr += 1;
         return r;
     }
@@ -392,6 +394,8 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
         s.ep_len = (int)(ep & 0xffffu);
         s.ep_ret = (int)ep >> 16;
     }
+
+    s.kc = s.key + s.ctr * 0x9E3779B9U;
 
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: F^T order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
