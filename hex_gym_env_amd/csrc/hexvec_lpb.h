@@ -1,4 +1,5 @@
-// hexvec_lpb.h -- lane-per-board ("LPB") kernels: the throughput path.
+// hexvec_lpb.h -- lane-per-board ("LPB") kernels: the layout of HEXVEC_F_ROLLOUT_LAYOUT handles
+// (the device-resident rollouts; every other entry point works on it too).
 //
 // Why a second kernel family: with one wavefront per board every index
 // computation of a ply is wave-uniform and lands on the CU's single scalar
@@ -13,13 +14,15 @@
 //                     six offsets).  0 = no stone of p; 1..C = child, parent
 //                     index + 1; 0xE0 | rank<<2 | f = root, f bit0/bit1 = its
 //                     group touches row 0 / row N-1.  A new stone reads its 6
-//                     neighbours, chases them to their roots (all chains of all
-//                     64 boards in lockstep), hangs itself and the lower-rank
-//                     roots under the highest-rank root (union by rank: the
-//                     wave-level chase depth stays ~2) and ORs the flags; the
-//                     mover wins iff the flags become 3.  That is plain connectivity, which SURVEY 4
-//                     verified equals the reference's label merging
-//                     (HexGame.py:124-142 + :101-105).
+//                     neighbours, keeps ONE cell per run of p-stones around that
+//                     ring (ring-adjacent stones already share a root; at most
+//                     three groups can meet at a hex cell), chases those <= 3
+//                     chains to their roots (all chains of all 64 boards in
+//                     lockstep), hangs itself and the lower-rank roots under the
+//                     highest-rank root (union by rank keeps the chains short) and
+//                     ORs the flags; the mover wins iff the flags become 3.  That
+//                     is plain connectivity, which SURVEY 4 verified equals the
+//                     reference's label merging (HexGame.py:124-142 + :101-105).
 //   IMG[v][board][C]  the observation bytes themselves, packed exactly as the
 //                     [E, N*N] output rows.  Encoding B shows the board in the
 //                     mover's perspective (HexSingleGame.py:265-271: BLACK to move
@@ -36,7 +39,8 @@
 //
 // Empty-cell bitboards (one per frame) stay in registers for the uniform
 // random policy (k-th set bit) and the legality test.  Scalars (action,
-// reward, done) are one coalesced store per wave.
+// reward, done) are one coalesced store per wave (in the self-play rollout the helper
+// wavefront stores them together with the observation rows).
 //
 // Scope: handles with auto reset.  Then no ply is ever applied after the end
 // of a game and an illegal action ends the episode at once, so the literal

@@ -34,7 +34,7 @@ for two in (True, False):
     for rnd in range(int(os.environ.get("ROUNDS", 3))):
       for name, out in (("all", full), ("none", {})):
         ms = timeit(lambda: fn(T, out))
-        print(os.path.basename(os.environ.get("HEXVEC_SO", "libhexvec.so")), "%s bpw=%s %-9s %.3f ms/launch  %.2f G units/s" % ("W2" if two else "W1", os.environ.get("HEXVEC_BPW", "auto"), name, ms, E * T / ms / 1e6))
+        print(os.path.basename(os.environ.get("HEXVEC_SO", "libhexvec.so")), "%s %-9s %.3f ms/launch  %.2f G units/s" % ("W2" if two else "W1", name, ms, E * T / ms / 1e6))
     if not two:
         ms = timeit(lambda: env.step(), n=300)
         print(os.path.basename(os.environ.get("HEXVEC_SO", "libhexvec.so")), "host-stepped step: %.2f us/step  %.2f G steps/s" % (ms * 1e3, E / ms / 1e6))
