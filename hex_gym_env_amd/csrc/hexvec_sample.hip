@@ -1,0 +1,114 @@
+// hexvec_sample.hip -- one categorical sample per row from softmax(logits) restricted to legal != 0:
+// what OpponentPolicy.choose_action obtains from model.predict(board, action_masks=mask)
+// (SelfplayWrapper.py:26-35; SB3's masked categorical) and, with logits == NULL, the uniform choice of
+// BaseRandomPolicy.choose_action (SelfplayWrapper.py:16-24) -- for every board of a batch in ONE launch
+// (the torch formulation is eight small kernels per policy call: rand, 2 x log, clamp, add, where, max,
+// counting; three policy calls per self-play collection step).
+//
+// Gumbel-max: argmax_c (logit_c + G_c), G_c = -log(-log(u_c)), u_c uniform in (0,1) from a counter hash
+// of (seed, draw counter, row, c) -- the same distribution as sampling softmax(logits) over the legal cells.
+// One 16-lane DPP row of a wavefront owns one logits row: lane s takes cells s, s+16, ...; value and index
+// are reduced with DPP row shuffles.  A row that cannot be sampled (no legal cell, NaN logit on a legal
+// cell, all legal logits -inf) yields action 0 and is counted in *bad_rows.  The draw counter lives on the
+// device and is advanced by the last workgroup to finish, so a captured graph draws fresh numbers on every
+// replay without any host involvement.
+#include "hexvec_common.h"
+
+namespace hv {
+
+__device__ __forceinline__ float dpp_f(float x, int sel)
+{
+    // lane i reads lane i ^ sel of its 16-lane row (sel = 1, 2: quad permutes; 4, 8: row rotations)
+    int v = __float_as_int(x);
+    switch (sel) {
+    case 1: v = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); break;  // quad_perm [1,0,3,2]
+    case 2: v = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true); break;  // quad_perm [2,3,0,1]
+    case 4: v = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: v = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return __int_as_float(v);
+}
+__device__ __forceinline__ int dpp_i(int x, int sel) { return __float_as_int(dpp_f(__int_as_float(x), sel)); }
+
+// state[0] = draw counter, state[1] = workgroups finished (ticket)
+__global__ __launch_bounds__(256) void k_sample_masked(const float *logits, const unsigned char *legal, int rows,
+                                                       int cols, u32 seed_lo, u32 seed_hi, unsigned long long *state,
+                                                       int *actions, unsigned long long *bad_rows)
+{
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int row = tid >> 4, sub = tid & 15;
+    const unsigned long long ctr = state[0];
+    const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
+    if (row < rows) { // a 16-lane row is all in or all out
+        const size_t base = (size_t)row * (size_t)cols;
+        const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U);
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+        bool bad = false;
+        for (int c = sub; c < cols; c += 16) {
+            if (legal[base + c] == 0) continue;
+            const float z = logits ? logits[base + c] : 0.0f;
+            const u32 h = mix32(rkey + (u32)c * 0x9E3779B9U);
+            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); // in (0, 1)
+            const float v = z - __logf(-__logf(u));
+            bad = bad || (z != z);
+            if (v > best) {
+                best = v;
+                besti = c;
+            }
+        }
+        // (value, index) maximum over the 16 lanes of the row; ties go to the lower index
+#pragma unroll
+        for (int sel = 1; sel <= 8; sel <<= 1) {
+            const float ob = dpp_f(best, sel);
+            const int oi = dpp_i(besti, sel);
+            const int obad = dpp_i(bad ? 1 : 0, sel);
+            const bool take = ob > best || (ob == best && oi < besti);
+            best = take ? ob : best;
+            besti = take ? oi : besti;
+            bad = bad || obad != 0;
+        }
+        if (sub == 0) {
+            const bool degenerate = bad || !(best > -INFINITY);
+            actions[row] = degenerate ? 0 : besti;
+            if (degenerate && bad_rows) atomicAdd(bad_rows, 1ULL);
+        }
+    }
+    // the last workgroup to finish advances the draw counter (everybody has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned long long t = atomicAdd(&state[1], 1ULL);
+        if (t == (unsigned long long)gridDim.x - 1ULL) {
+            state[1] = 0ULL;
+            state[0] = ctr + 1ULL;
+            __threadfence();
+        }
+    }
+}
+
+} // namespace hv
+
+static thread_local char g_serr[256] = "";
+extern "C" const char *hexvec_sample_last_error(void) { return g_serr; }
+
+extern "C" int hexvec_sample_masked(const float *logits, const uint8_t *legal, int rows, int cols, uint64_t seed,
+                                    unsigned long long *state2, int32_t *actions, unsigned long long *bad_rows,
+                                    void *stream)
+{
+    if (!legal || !actions || !state2 || rows < 0 || cols < 1) {
+        snprintf(g_serr, sizeof(g_serr), "%s", "hexvec_sample_masked: legal / actions / state NULL or bad shape");
+        return HEXVEC_E_ARG;
+    }
+    if (rows == 0) return HEXVEC_OK;
+    const long long threads = (long long)rows * 16;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, legal, rows, cols,
+                       (hv::u32)seed, (hv::u32)(seed >> 32), state2, actions, bad_rows);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_serr, sizeof(g_serr), "hexvec_sample_masked: %s", hipGetErrorString(e));
+        return HEXVEC_E_HIP;
+    }
+    return HEXVEC_OK;
+}

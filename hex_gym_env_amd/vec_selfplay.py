@@ -10,7 +10,7 @@ ply.  Here every board has its own opponent slot; one env step is
 repeated while boards are pending (a second round plays the openings of boards that were reset
 with the opponent to move first).  All tensors stay on the GPU.
 
-Policies are objects with  choose_actions(obs int8 [B,N,N], legal uint8 [B,N*N]) -> int64 [B]
+Policies are objects with  choose_actions(obs int8 [B,N,N], legal uint8 [B,N*N]) -> int32 / int64 [B]
 (the batched form of OpponentPolicy.choose_action(board, action_mask), :26-35):
 RandomLegalPolicy (BaseRandomPolicy, :16-24) and MlpActorPolicy (an SB3 MaskablePPO "MlpPolicy"
 actor, loadable from the reference's shipped checkpoints with weights_only=True).
@@ -58,22 +58,51 @@ def sample_boards(board_size, count, generator, device):
     return board.view(count, n, n)
 
 
-def sample_masked(logits, legal, generator=None, bad_rows=None):
-    """One categorical sample per row from softmax(logits) restricted to legal != 0, by the Gumbel-max
-    trick: argmax(logits + G).  Same distribution as multinomial(softmax(masked logits)) but without
-    torch.multinomial's device-side assertion, so it can be captured in a hipGraph.
-
-    A DEGENERATE row -- no legal cell, or a NaN logit on a legal cell -- cannot be sampled; it yields
-    an arbitrary action (an illegal ply ends the episode with reward 0) and is COUNTED in `bad_rows`
-    (int64 scalar on the device, incremented in place) so that it never passes silently: the policies
-    below own such a counter and VecSelfPlayEnv.degenerate_rows() reads them."""
-    u = torch.rand(logits.shape, generator=generator, device=logits.device, dtype=torch.float32)
+def sample_masked_torch(logits, legal, generator=None, bad_rows=None):
+    """sample_masked() spelled in torch ops (eight small kernels): the distribution reference of the tests"""
+    u = torch.rand(legal.shape, generator=generator, device=legal.device, dtype=torch.float32)
     g = -torch.log(-torch.log(u.clamp_(1e-20, 1.0 - 1e-7)))
-    z = torch.where(legal != 0, logits.float() + g, torch.full_like(g, float("-inf")))
+    z = g if logits is None else logits.float() + g
+    z = torch.where(legal != 0, z, torch.full_like(g, float("-inf")))
     best, idx = z.max(1)            # one kernel for value and index
     if bad_rows is not None:        # a row without a legal cell peaks at -inf, one with a NaN logit at NaN
         bad_rows.add_((~(best > float("-inf"))).sum())
     return idx
+
+
+_SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, ticket} of hexvec_sample_masked
+
+
+def sample_masked(logits, legal, generator=None, bad_rows=None):
+    """One categorical sample per row from softmax(logits) restricted to legal != 0 (logits None = uniform over
+    the legal cells), by the Gumbel-max trick argmax(logits + G): ONE libhexvec launch per call
+    (hexvec_sample_masked, include/hexvec.h), no device-side assertion, capturable in a hipGraph -- the draw
+    counter lives on the device and advances with every launch, also under graph replay.  `generator` only
+    names the random stream (its initial seed keys the counter hash); torch's own stream is not consumed.
+
+    A DEGENERATE row -- no legal cell, or a NaN logit on a legal cell -- cannot be sampled; it yields
+    action 0 (an illegal ply ends the episode with reward 0) and is COUNTED in `bad_rows` (int64 scalar on
+    the device, incremented by the kernel) so that it never passes silently: the policies below own such a
+    counter and VecSelfPlayEnv.degenerate_rows() reads them.  Returns int32 [rows]."""
+    import ctypes as C
+    from . import _lib
+    if not legal.is_cuda:
+        raise RuntimeError("sample_masked runs on the GPU only (libhexvec has no CPU path)")
+    rows, cols = legal.shape
+    lg = legal if legal.dtype == torch.uint8 and legal.is_contiguous() else legal.to(torch.uint8).contiguous()
+    lo = None
+    if logits is not None:
+        lo = logits if logits.dtype == torch.float32 and logits.is_contiguous() else logits.float().contiguous()
+    key = (legal.device, id(generator))
+    st = _SAMPLER_STATE.get(key)
+    if st is None:
+        st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=legal.device)
+    seed = (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1)
+    out = torch.empty(rows, dtype=torch.int32, device=legal.device)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _lib.check(_lib.lib().hexvec_sample_masked(p(lo), p(lg), rows, cols, C.c_uint64(seed), p(st), p(out), p(bad_rows),
+                                               C.c_void_p(torch.cuda.current_stream(legal.device).cuda_stream)))
+    return out
 
 
 class _CountsBadRows:
@@ -97,8 +126,7 @@ class RandomLegalPolicy(_CountsBadRows):
         return ("random-legal", id(self.generator))
 
     def choose_actions(self, obs, legal):
-        return sample_masked(torch.zeros(legal.shape, device=legal.device), legal, self.generator,
-                             self.bad_rows_counter(legal.device))
+        return sample_masked(None, legal, self.generator, self.bad_rows_counter(legal.device))
 
     def save_model(self, path):
         return None
@@ -155,7 +183,7 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
     @torch.no_grad()
     def choose_actions(self, obs, legal):
         if self.deterministic:
-            return self.logits(obs, legal).argmax(1)
+            return self.logits(obs, legal).argmax(1).to(torch.int32)
         x = obs.reshape(obs.shape[0], -1).float()
         return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator,
                              self.bad_rows_counter(legal.device))

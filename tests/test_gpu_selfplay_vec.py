@@ -571,3 +571,55 @@ def test_default_random_pool_is_one_policy_group(hx):
         mlp.action_net.bias[7] = float("nan")
     mlp.choose_actions(env.vec.obs[:8], torch.ones_like(legal))
     assert env.degenerate_rows(mlp) == 1 + 8
+
+
+def test_fused_masked_sampler_distribution_and_counter(hx):
+    """hexvec_sample_masked (one launch): never an illegal cell, frequencies == softmax over the legal cells
+    (and == the torch spelling's), uniform with logits None, fresh draws on every call and every graph
+    replay, degenerate rows counted"""
+    from hex_gym_env_amd.vec_selfplay import sample_masked, sample_masked_torch
+    torch.manual_seed(0)
+    R, Cc = 200000, 49
+    row = torch.randn(Cc, device="cuda") * 1.5
+    mask = (torch.rand(Cc, device="cuda") < 0.6).to(torch.uint8)
+    mask[3] = 1
+    logits, legal = row.expand(R, Cc).contiguous(), mask.expand(R, Cc).contiguous()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    bad = torch.zeros((), dtype=torch.long, device="cuda")
+    a = sample_masked(logits, legal, gen, bad)
+    assert a.dtype == torch.int32 and a.shape == (R,) and int(bad) == 0
+    assert bool(mask[a.long()].all())                              # only legal cells
+    p = torch.softmax(row.masked_fill(mask == 0, float("-inf")), 0)
+    f = torch.bincount(a.long(), minlength=Cc).double() / R
+    assert float((f - p.double()).abs().max()) < 4e-3, float((f - p.double()).abs().max())
+    ft = torch.bincount(sample_masked_torch(logits, legal), minlength=Cc).double() / R
+    assert float((f - ft).abs().max()) < 6e-3
+    b = sample_masked(logits, legal, gen, bad)                      # the counter moved: new draws
+    assert float((a != b).double().mean()) > 0.5
+    u = sample_masked(None, legal, gen, bad)                        # uniform over the legal cells
+    fu = torch.bincount(u.long(), minlength=Cc).double() / R
+    assert float((fu - mask.double() / mask.sum()).abs().max()) < 4e-3
+    # under graph replay the draws keep changing (the counter lives on the device)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        sample_masked(logits, legal, gen, bad)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = sample_masked(logits, legal, gen, bad)
+    g.replay()
+    torch.cuda.synchronize()
+    first = out.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float((first != out).double().mean()) > 0.5 and bool(mask[out.long()].all())
+    # rows that cannot be sampled: counted, action 0
+    legal2 = legal[:64].clone()
+    legal2[5] = 0
+    lg2 = logits[:64].clone()
+    lg2[9, 3] = float("nan")
+    c = sample_masked(lg2, legal2, gen, bad)
+    assert int(bad) == 2 and int(c[5]) == 0 and int(c[9]) == 0
+    # odd shapes: one row, 169 columns
+    one = sample_masked(torch.zeros((1, 169), device="cuda"), torch.ones((1, 169), dtype=torch.uint8, device="cuda"), gen, bad)
+    assert 0 <= int(one[0]) < 169
