@@ -10,8 +10,8 @@
 // One 16-lane DPP row of a wavefront owns one logits row: lane s takes cells s, s+16, ...; value and index
 // are reduced with DPP row shuffles.  A row that cannot be sampled (no legal cell, NaN logit on a legal
 // cell, all legal logits -inf) yields action 0 and is counted in *bad_rows.  The draw counter lives on the
-// device and is advanced by the last workgroup to finish, so a captured graph draws fresh numbers on every
-// replay without any host involvement.
+// device and is advanced by a one-thread kernel behind the sampling kernel, so a captured graph draws fresh
+// numbers on every replay without any host involvement.
 #include "hexvec_common.h"
 
 namespace hv {
@@ -30,62 +30,66 @@ __device__ __forceinline__ float dpp_f(float x, int sel)
 }
 __device__ __forceinline__ int dpp_i(int x, int sel) { return __float_as_int(dpp_f(__int_as_float(x), sel)); }
 
-// state[0] = draw counter, state[1] = workgroups finished (ticket)
+// state[0] = draw counter (state[1] unused)
 __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, const unsigned char *legal, int rows,
-                                                       int cols, u32 seed_lo, u32 seed_hi, unsigned long long *state,
-                                                       int *actions, unsigned long long *bad_rows)
+                                                       int cols, u32 seed_lo, u32 seed_hi,
+                                                       const unsigned long long *state, int *actions,
+                                                       unsigned long long *bad_rows)
 {
-    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int row = tid >> 4, sub = tid & 15;
+    const int sub = (int)threadIdx.x & 15;
+    const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    if (row >= rows) return; // a 16-lane row is all in or all out
     const unsigned long long ctr = state[0];
     const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
-    if (row < rows) { // a 16-lane row is all in or all out
-        const size_t base = (size_t)row * (size_t)cols;
-        const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U);
-        float best = -INFINITY;
-        int besti = 0x7fffffff;
-        bool bad = false;
-        for (int c = sub; c < cols; c += 16) {
-            if (legal[base + c] == 0) continue;
-            const float z = logits ? logits[base + c] : 0.0f;
+    const size_t base = (size_t)row * (size_t)cols;
+    const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U);
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    bool bad = false;
+    for (int c0 = sub; c0 < cols; c0 += 64) { // four cells per lane and trip, their loads issued together
+        unsigned char lg[4];
+        float z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + 16 * k;
+            lg[k] = c < cols ? legal[base + c] : (unsigned char)0;
+            z[k] = (logits && c < cols) ? logits[base + c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + 16 * k;
             const u32 h = mix32(rkey + (u32)c * 0x9E3779B9U);
             const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); // in (0, 1)
-            const float v = z - __logf(-__logf(u));
-            bad = bad || (z != z);
-            if (v > best) {
+            const float v = z[k] - __logf(-__logf(u));
+            const bool on = lg[k] != 0;
+            bad = bad || (on && z[k] != z[k]);
+            if (on && v > best) {
                 best = v;
                 besti = c;
             }
         }
-        // (value, index) maximum over the 16 lanes of the row; ties go to the lower index
-#pragma unroll
-        for (int sel = 1; sel <= 8; sel <<= 1) {
-            const float ob = dpp_f(best, sel);
-            const int oi = dpp_i(besti, sel);
-            const int obad = dpp_i(bad ? 1 : 0, sel);
-            const bool take = ob > best || (ob == best && oi < besti);
-            best = take ? ob : best;
-            besti = take ? oi : besti;
-            bad = bad || obad != 0;
-        }
-        if (sub == 0) {
-            const bool degenerate = bad || !(best > -INFINITY);
-            actions[row] = degenerate ? 0 : besti;
-            if (degenerate && bad_rows) atomicAdd(bad_rows, 1ULL);
-        }
     }
-    // the last workgroup to finish advances the draw counter (everybody has read it by then)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned long long t = atomicAdd(&state[1], 1ULL);
-        if (t == (unsigned long long)gridDim.x - 1ULL) {
-            state[1] = 0ULL;
-            state[0] = ctr + 1ULL;
-            __threadfence();
-        }
+    // (value, index) maximum over the 16 lanes of the row; ties go to the lower index
+#pragma unroll
+    for (int sel = 1; sel <= 8; sel <<= 1) {
+        const float ob = dpp_f(best, sel);
+        const int oi = dpp_i(besti, sel);
+        const int obad = dpp_i(bad ? 1 : 0, sel);
+        const bool take = ob > best || (ob == best && oi < besti);
+        best = take ? ob : best;
+        besti = take ? oi : besti;
+        bad = bad || obad != 0;
+    }
+    if (sub == 0) {
+        const bool degenerate = bad || !(best > -INFINITY);
+        actions[row] = degenerate ? 0 : besti;
+        if (degenerate && bad_rows) atomicAdd(bad_rows, 1ULL);
     }
 }
+// advances the draw counter once every sampling workgroup is done (a kernel of its own: the stream
+// orders it behind them, also inside a captured graph; a ticket per workgroup would serialise
+// thousands of atomics on one word)
+__global__ void k_sample_bump(unsigned long long *state) { state[0] += 1ULL; }
 
 } // namespace hv
 
@@ -105,6 +109,7 @@ extern "C" int hexvec_sample_masked(const float *logits, const uint8_t *legal, i
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, legal, rows, cols,
                        (hv::u32)seed, (hv::u32)(seed >> 32), state2, actions, bad_rows);
+    hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_serr, sizeof(g_serr), "hexvec_sample_masked: %s", hipGetErrorString(e));

@@ -70,7 +70,7 @@ def sample_masked_torch(logits, legal, generator=None, bad_rows=None):
     return idx
 
 
-_SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, ticket} of hexvec_sample_masked
+_SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, reserved} of hexvec_sample_masked
 
 
 def sample_masked(logits, legal, generator=None, bad_rows=None):

@@ -218,7 +218,7 @@ int hexvec_stream_synchronize(hexvec_t *h, void *stream);
  * (SelfplayWrapper.py:16-24).  logits float32 [rows, cols] (or NULL), legal uint8 [rows, cols], actions int32
  * [rows], all device pointers.  Random numbers: Gumbel-max with a counter hash of (seed, draw counter, row,
  * column); state2 = two device uint64 words owned by the caller and zeroed once {draw counter, internal
- * ticket}: the kernel advances the counter itself, so a captured graph draws fresh numbers on every replay.
+ * reserved}: the call advances the counter on the device, so a captured graph draws fresh numbers on every replay.
  * A row that cannot be sampled (no legal cell, NaN logit on a legal cell) yields action 0 and adds 1 to
  * *bad_rows (device uint64, may be NULL).  Not the reference's Mersenne-Twister / torch stream: the
  * distribution is the same, the draws are not. */
