@@ -344,7 +344,8 @@ def test_sb3_adapter_with_opponent_buffer_and_callback_surface(hx):
     venv.close()
 
 
-def test_prewon_start_position_is_noticed_on_the_next_ply(hx):
+@LAYOUTS
+def test_prewon_start_position_is_noticed_on_the_next_ply(hx, lay):
     """quirk q9: a start position in which a colour is already connected ends the game on that
     colour's next ply wherever it is played (the reference tests regions[cur][-1,-1] after every move
     of the mover, HexGame.py:101-105) -- fast path == exact engine"""
@@ -353,7 +354,7 @@ def test_prewon_start_position_is_noticed_on_the_next_ply(hx):
     b[:, :, 2] = -1                      # BLACK column: top-bottom connected
     b[:, 0, 0] = 1
     b[:, 4, 4] = 1                       # some WHITE stones, not connected
-    fast = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=1, auto_reset=True)
+    fast = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=1, auto_reset=True, rollout_layout=lay)
     exact = hx.HexVecEnv(n, E, encoding="B", two_sided=True, seed=1, exact_labels=True)
     fast.set_boards(b)
     exact.set_state(b.reshape(E, -1))
