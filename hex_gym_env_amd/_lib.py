@@ -81,7 +81,7 @@ def lib():
     L.hexvec_export_state.argtypes = [vp, vp, vp]
     L.hexvec_import_state.argtypes = [vp, vp, vp]
     L.hexvec_stream_synchronize.argtypes = [vp, vp]
-    L.hexvec_sample_masked.argtypes = [vp, vp, i32, i32, u64, vp, vp, vp, vp]
+    L.hexvec_sample_masked.argtypes = [vp, C.c_longlong, vp, vp, i32, i32, u64, vp, vp, vp, vp]
     L.hexvec_board_size.argtypes = [vp]
     L.hexvec_num_envs.argtypes = [vp]
     L.hexvec_flags.argtypes = [vp]

@@ -31,17 +31,23 @@ __device__ __forceinline__ float dpp_f(float x, int sel)
 __device__ __forceinline__ int dpp_i(int x, int sel) { return __float_as_int(dpp_f(__int_as_float(x), sel)); }
 
 // state[0] = draw counter (state[1] unused)
-__global__ __launch_bounds__(256) void k_sample_masked(const float *logits, const unsigned char *legal, int rows,
-                                                       int cols, u32 seed_lo, u32 seed_hi,
+__global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long long logits_row_stride,
+                                                       const unsigned char *legal, const unsigned char *row_active,
+                                                       int rows, int cols, u32 seed_lo, u32 seed_hi,
                                                        const unsigned long long *state, int *actions,
                                                        unsigned long long *bad_rows)
 {
     const int sub = (int)threadIdx.x & 15;
     const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
     if (row >= rows) return; // a 16-lane row is all in or all out
+    if (row_active && row_active[row] == 0) { // nobody asked for this board's action
+        if (sub == 0) actions[row] = 0;
+        return;
+    }
     const unsigned long long ctr = state[0];
     const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
     const size_t base = (size_t)row * (size_t)cols;
+    const size_t lbase = (size_t)row * (size_t)logits_row_stride; // stride 0: every board shares one logits row
     const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U);
     float best = -INFINITY;
     int besti = 0x7fffffff;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, cons
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + 16 * k;
             lg[k] = c < cols ? legal[base + c] : (unsigned char)0;
-            z[k] = (logits && c < cols) ? logits[base + c] : 0.0f;
+            z[k] = (logits && c < cols) ? logits[lbase + c] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -96,7 +102,8 @@ __global__ void k_sample_bump(unsigned long long *state) { state[0] += 1ULL; }
 static thread_local char g_serr[256] = "";
 extern "C" const char *hexvec_sample_last_error(void) { return g_serr; }
 
-extern "C" int hexvec_sample_masked(const float *logits, const uint8_t *legal, int rows, int cols, uint64_t seed,
+extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_stride, const uint8_t *legal,
+                                    const uint8_t *row_active, int rows, int cols, uint64_t seed,
                                     unsigned long long *state2, int32_t *actions, unsigned long long *bad_rows,
                                     void *stream)
 {
@@ -107,8 +114,8 @@ extern "C" int hexvec_sample_masked(const float *logits, const uint8_t *legal, i
     if (rows == 0) return HEXVEC_OK;
     const long long threads = (long long)rows * 16;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, legal, rows, cols,
-                       (hv::u32)seed, (hv::u32)(seed >> 32), state2, actions, bad_rows);
+    hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, logits_row_stride,
+                       legal, row_active, rows, cols, (hv::u32)seed, (hv::u32)(seed >> 32), state2, actions, bad_rows);
     hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

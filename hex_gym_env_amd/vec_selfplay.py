@@ -73,12 +73,14 @@ def sample_masked_torch(logits, legal, generator=None, bad_rows=None):
 _SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, reserved} of hexvec_sample_masked
 
 
-def sample_masked(logits, legal, generator=None, bad_rows=None):
+def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None, out=None):
     """One categorical sample per row from softmax(logits) restricted to legal != 0 (logits None = uniform over
-    the legal cells), by the Gumbel-max trick argmax(logits + G): ONE libhexvec launch per call
-    (hexvec_sample_masked, include/hexvec.h), no device-side assertion, capturable in a hipGraph -- the draw
-    counter lives on the device and advances with every launch, also under graph replay.  `generator` only
-    names the random stream (its initial seed keys the counter hash); torch's own stream is not consumed.
+    the legal cells; a [1, C] logits row is shared by all boards), by the Gumbel-max trick argmax(logits + G):
+    ONE libhexvec call (hexvec_sample_masked, include/hexvec.h), no device-side assertion, capturable in a
+    hipGraph -- the draw counter lives on the device and advances with every call, also under graph replay.
+    `generator` only names the random stream (its initial seed keys the counter hash); torch's own stream is
+    not consumed.  row_active (uint8 / bool [rows], optional): boards with 0 get action 0 and are skipped.
+    out (int32 [rows], optional): where to write the actions.
 
     A DEGENERATE row -- no legal cell, or a NaN logit on a legal cell -- cannot be sampled; it yields
     action 0 (an illegal ply ends the episode with reward 0) and is COUNTED in `bad_rows` (int64 scalar on
@@ -90,24 +92,36 @@ def sample_masked(logits, legal, generator=None, bad_rows=None):
         raise RuntimeError("sample_masked runs on the GPU only (libhexvec has no CPU path)")
     rows, cols = legal.shape
     lg = legal if legal.dtype == torch.uint8 and legal.is_contiguous() else legal.to(torch.uint8).contiguous()
-    lo = None
+    lo, stride = None, 0
     if logits is not None:
-        lo = logits if logits.dtype == torch.float32 and logits.is_contiguous() else logits.float().contiguous()
+        if logits.shape[0] == 1 or (logits.dim() == 2 and logits.stride(0) == 0):   # one row for every board
+            lo = logits[:1].float().contiguous()
+        else:
+            lo = logits if logits.dtype == torch.float32 and logits.is_contiguous() else logits.float().contiguous()
+            stride = cols
+    ra = None
+    if row_active is not None:
+        ra = row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)
+        ra = ra.contiguous()
     key = (legal.device, id(generator))
     st = _SAMPLER_STATE.get(key)
     if st is None:
         st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=legal.device)
     seed = (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1)
-    out = torch.empty(rows, dtype=torch.int32, device=legal.device)
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int32, device=legal.device)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-    _lib.check(_lib.lib().hexvec_sample_masked(p(lo), p(lg), rows, cols, C.c_uint64(seed), p(st), p(out), p(bad_rows),
+    _lib.check(_lib.lib().hexvec_sample_masked(p(lo), stride, p(lg), p(ra), rows, cols, C.c_uint64(seed), p(st), p(out),
+                                               p(bad_rows),
                                                C.c_void_p(torch.cuda.current_stream(legal.device).cuda_stream)))
     return out
 
 
 class _CountsBadRows:
-    """per-policy device counter of degenerate sampling rows (see sample_masked)"""
+    """per-policy device counter of degenerate sampling rows (see sample_masked); such policies also take
+    choose_actions(obs, legal, row_active=..., out=...) (boards to skip / where to write)"""
     _bad_rows = None
+    takes_row_active = True
 
     def bad_rows_counter(self, device):
         if self._bad_rows is None or self._bad_rows.device != torch.device(device):
@@ -125,8 +139,8 @@ class RandomLegalPolicy(_CountsBadRows):
         """policies with equal keys answer identically distributed and may share one batched call"""
         return ("random-legal", id(self.generator))
 
-    def choose_actions(self, obs, legal):
-        return sample_masked(None, legal, self.generator, self.bad_rows_counter(legal.device))
+    def choose_actions(self, obs, legal, row_active=None, out=None):
+        return sample_masked(None, legal, self.generator, self.bad_rows_counter(legal.device), row_active, out)
 
     def save_model(self, path):
         return None
@@ -181,12 +195,13 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         return z.masked_fill(legal == 0, float("-inf"))
 
     @torch.no_grad()
-    def choose_actions(self, obs, legal):
+    def choose_actions(self, obs, legal, row_active=None, out=None):
         if self.deterministic:
-            return self.logits(obs, legal).argmax(1).to(torch.int32)
+            a = self.logits(obs, legal).argmax(1).to(torch.int32)
+            return a if out is None else out.copy_(a)
         x = obs.reshape(obs.shape[0], -1).float()
         return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator,
-                             self.bad_rows_counter(legal.device))
+                             self.bad_rows_counter(legal.device), row_active, out)
 
     def save_model(self, path):
         torch.save(self.state_dict(), path)
@@ -292,9 +307,14 @@ class VecSelfPlayEnv:
         """actions of every pending board's opponent: each distinct policy group is evaluated on the
         whole batch and its answers are kept where that policy is the opponent."""
         groups = self._groups()
-        safe_legal = torch.where(pending.view(-1, 1).bool(), legal, torch.ones_like(legal))
+        safe_legal = None
         first = True
         for pol, slots in groups.values():
+            if getattr(pol, "takes_row_active", False) and len(groups) == 1:      # the sampler skips the boards that owe no ply and writes in place
+                pol.choose_actions(obs, legal, row_active=pending, out=self._opp)
+                return
+            if safe_legal is None:              # generic policies: boards that owe no ply look all-legal to them
+                safe_legal = torch.where(pending.view(-1, 1).bool(), legal, torch.ones_like(legal))
             a = pol.choose_actions(obs, safe_legal).to(torch.int32)
             if first and len(groups) == 1:
                 self._opp.copy_(a)
@@ -303,7 +323,7 @@ class VecSelfPlayEnv:
             member = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
             for k in slots:
                 member |= self.slot == k
-            self._opp.copy_(torch.where(member, a, self._opp))
+            torch.where(member, a, self._opp, out=self._opp)
 
     def _opening_actions(self):
         """openings on EMPTY boards: every board that shares a policy has the same distribution, so a
@@ -313,10 +333,12 @@ class VecSelfPlayEnv:
         full = self._all_legal
         for pol, slots in groups.values():
             if hasattr(pol, "logits"):
-                z = pol.logits(self._empty_board[:1], full[:1])
-                a = sample_masked(z.expand(E, -1), full, getattr(pol, "generator", None),
-                                  pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter")
-                                  else None).to(torch.int32)
+                z = pol.logits(self._empty_board[:1], full[:1])     # one row, shared by every board
+                a = sample_masked(z, full, getattr(pol, "generator", None),
+                                  pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter") else None,
+                                  out=self._opp if len(groups) == 1 else None)
+                if len(groups) == 1:
+                    return
             else:
                 a = pol.choose_actions(self._empty_board, full).to(torch.int32)
             if len(groups) == 1:

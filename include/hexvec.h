@@ -215,15 +215,18 @@ int hexvec_stream_synchronize(hexvec_t *h, void *stream);
  * One categorical sample per row from softmax(logits[r, :]) restricted to legal[r, c] != 0 -- what
  * OpponentPolicy.choose_action gets from model.predict(board, deterministic=False, action_masks=mask)
  * (SelfplayWrapper.py:26-35); logits == NULL = uniform over the legal cells, BaseRandomPolicy.choose_action
- * (SelfplayWrapper.py:16-24).  logits float32 [rows, cols] (or NULL), legal uint8 [rows, cols], actions int32
- * [rows], all device pointers.  Random numbers: Gumbel-max with a counter hash of (seed, draw counter, row,
- * column); state2 = two device uint64 words owned by the caller and zeroed once {draw counter, internal
- * reserved}: the call advances the counter on the device, so a captured graph draws fresh numbers on every replay.
- * A row that cannot be sampled (no legal cell, NaN logit on a legal cell) yields action 0 and adds 1 to
- * *bad_rows (device uint64, may be NULL).  Not the reference's Mersenne-Twister / torch stream: the
- * distribution is the same, the draws are not. */
-int hexvec_sample_masked(const float *logits, const uint8_t *legal, int rows, int cols, uint64_t seed,
-                         unsigned long long *state2, int32_t *actions, unsigned long long *bad_rows, void *stream);
+ * (SelfplayWrapper.py:16-24).  logits float32, row r at logits + r * logits_row_stride (elements; 0 = all boards
+ * share one row, e.g. the opening on an empty board), or NULL; legal uint8 [rows, cols]; row_active uint8 [rows]
+ * or NULL: boards whose byte is 0 get action 0 and are neither sampled nor counted (the boards that owe no
+ * opponent ply in this round); actions int32 [rows]; all device pointers.  Random numbers: Gumbel-max with a
+ * counter hash of (seed, draw counter, row, column); state2 = two device uint64 words owned by the caller and
+ * zeroed once {draw counter, reserved}: the call advances the counter on the device, so a captured graph draws
+ * fresh numbers on every replay.  A row that cannot be sampled (no legal cell, NaN logit on a legal cell) yields
+ * action 0 and adds 1 to *bad_rows (device uint64, may be NULL).  Not the reference's Mersenne-Twister / torch
+ * stream: the distribution is the same, the draws are not. */
+int hexvec_sample_masked(const float *logits, long long logits_row_stride, const uint8_t *legal,
+                         const uint8_t *row_active, int rows, int cols, uint64_t seed, unsigned long long *state2,
+                         int32_t *actions, unsigned long long *bad_rows, void *stream);
 
 int hexvec_board_size(const hexvec_t *h);
 int hexvec_num_envs(const hexvec_t *h);

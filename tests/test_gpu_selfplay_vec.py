@@ -621,6 +621,14 @@ def test_fused_masked_sampler_distribution_and_counter(hx):
     lg2[9, 3] = float("nan")
     c = sample_masked(lg2, legal2, gen, bad)
     assert int(bad) == 2 and int(c[5]) == 0 and int(c[9]) == 0
+    # boards to skip, a logits row shared by every board, actions written in place
+    act = torch.zeros(R, dtype=torch.uint8, device="cuda")
+    act[::2] = 1
+    dst = torch.full((R,), -7, dtype=torch.int32, device="cuda")
+    r = sample_masked(row.view(1, Cc), legal, gen, bad, row_active=act, out=dst)
+    assert r.data_ptr() == dst.data_ptr() and bool((dst[1::2] == 0).all()) and bool(mask[dst[::2].long()].all())
+    fs = torch.bincount(dst[::2].long(), minlength=Cc).double() / (R // 2)
+    assert float((fs - p.double()).abs().max()) < 6e-3 and int(bad) == 0
     # odd shapes: one row, 169 columns
     one = sample_masked(torch.zeros((1, 169), device="cuda"), torch.ones((1, 169), dtype=torch.uint8, device="cuda"), gen, bad)
     assert 0 <= int(one[0]) < 169
