@@ -628,7 +628,7 @@ def test_fused_masked_sampler_distribution_and_counter(hx):
     r = sample_masked(row.view(1, Cc), legal, gen, bad, row_active=act, out=dst)
     assert r.data_ptr() == dst.data_ptr() and bool((dst[1::2] == 0).all()) and bool(mask[dst[::2].long()].all())
     fs = torch.bincount(dst[::2].long(), minlength=Cc).double() / (R // 2)
-    assert float((fs - p.double()).abs().max()) < 6e-3 and int(bad) == 0
+    assert float((fs - p.double()).abs().max()) < 6e-3 and int(bad) == 2      # nothing new was counted
     # odd shapes: one row, 169 columns
     one = sample_masked(torch.zeros((1, 169), device="cuda"), torch.ones((1, 169), dtype=torch.uint8, device="cuda"), gen, bad)
     assert 0 <= int(one[0]) < 169
