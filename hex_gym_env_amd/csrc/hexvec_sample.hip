@@ -97,6 +97,33 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long
 // thousands of atomics on one word)
 __global__ void k_sample_bump(unsigned long long *state) { state[0] += 1ULL; }
 
+// SelfPlayEnv.setup_opponents for the boards that start a new episode (see hexvec_pick_opponents)
+__global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int when, const unsigned char *done,
+                                                        const unsigned char *pending, unsigned char *ended,
+                                                        const unsigned char *white, int rows, float prob_best,
+                                                        int pool_size, u32 seed_lo, u32 seed_hi,
+                                                        const unsigned long long *state)
+{
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= rows) return;
+    bool sel;
+    if (when == 0) {
+        const bool d = done[e] != 0;
+        ended[e] = d ? 1 : 0;
+        sel = d && pending[e] == 0;
+    } else if (when == 1) {
+        sel = pending[e] == 2;
+    } else {
+        sel = done[e] != 0 && ended[e] == 0 && white[e] == 0;
+    }
+    if (!sel) return;
+    const unsigned long long ctr = state[0];
+    const u32 k = mix32(((u32)e + (u32)ctr * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ ((u32)(ctr >> 32) * 0xC2B2AE35U);
+    const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const u32 member = __umulhi(mix32(k + 0x9E3779B9U), (u32)pool_size);
+    slot[e] = u < prob_best ? -1LL : (long long)member;
+}
+
 } // namespace hv
 
 static thread_local char g_serr[256] = "";
@@ -120,6 +147,29 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_serr, sizeof(g_serr), "hexvec_sample_masked: %s", hipGetErrorString(e));
+        return HEXVEC_E_HIP;
+    }
+    return HEXVEC_OK;
+}
+
+extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const uint8_t *pending,
+                                     uint8_t *ended, const uint8_t *white, int rows, float prob_best, int pool_size,
+                                     uint64_t seed, unsigned long long *state2, void *stream)
+{
+    const bool ok = slot && state2 && rows >= 0 && pool_size >= 1 && when >= 0 && when <= 2 &&
+                    (when == 0 ? (done && pending && ended) : when == 1 ? pending != nullptr : (done && ended && white));
+    if (!ok) {
+        snprintf(g_serr, sizeof(g_serr), "%s", "hexvec_pick_opponents: NULL argument or bad `when` / shape");
+        return HEXVEC_E_ARG;
+    }
+    if (rows == 0) return HEXVEC_OK;
+    hipLaunchKernelGGL(hv::k_pick_opponents, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long *)slot, when, done, pending, ended, white, rows, prob_best, pool_size, (hv::u32)seed,
+                       (hv::u32)(seed >> 32), state2);
+    hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_serr, sizeof(g_serr), "hexvec_pick_opponents: %s", hipGetErrorString(e));
         return HEXVEC_E_HIP;
     }
     return HEXVEC_OK;

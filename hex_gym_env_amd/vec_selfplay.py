@@ -262,6 +262,12 @@ class VecSelfPlayEnv:
         self._white = self.vec.agent_colours() != 0       # fixed per board (SelfplayWrapper.py:72-73)
         self._any_white = bool(self._white.any())          # one host read, at construction
         self._eval_cursor = torch.zeros((), dtype=torch.long, device=self.device)
+        # hexvec_pick_opponents: the boards' "ended on the agent's ply" bytes, the agents' colours as bytes,
+        # the draw counter of the slot choice
+        self._ended = torch.zeros(num_envs, dtype=torch.uint8, device=self.device)
+        self._white_u8 = self._white.to(torch.uint8)
+        self._pick_state = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._pick_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & (2 ** 64 - 1)
         self._empty_board = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8, device=self.device)
         self._all_legal = torch.ones((num_envs, board_size * board_size), dtype=torch.uint8, device=self.device)
 
@@ -302,6 +308,19 @@ class VecSelfPlayEnv:
             key = pol.group_key() if hasattr(pol, "group_key") else id(pol)
             groups.setdefault(key, (pol, []))[1].append(k)
         return groups
+
+    def _pick(self, when):
+        """setup_opponents (:97-104) for the boards that start a new episode at point `when` of the step, as
+        ONE libhexvec launch (hexvec_pick_opponents: the selection mask and the 80/20 draw are fused); the
+        evaluation walk (:92-96) needs a running count over the boards and keeps the torch spelling"""
+        import ctypes as C
+        from . import _lib
+        v = self.vec
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_lib.lib().hexvec_pick_opponents(
+            p(self.slot), when, p(v.done), p(v.pending), p(self._ended), p(self._white_u8), self.num_envs,
+            C.c_float(self.buffer.prob_best), len(self.buffer), C.c_uint64(self._pick_seed), p(self._pick_state),
+            C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def _opponent_actions(self, obs, legal, pending):
         """actions of every pending board's opponent: each distinct policy group is evaluated on the
@@ -397,6 +416,25 @@ class VecSelfPlayEnv:
         re-drawn before it opens (if it opens).  No host synchronisation: the number of opponent
         rounds is fixed (replies, then openings if any agent plays WHITE)."""
         self.vec.done.zero_()        # the split calls write only the boards whose step completes
+        if self.buffer.evaluating or self.sample_board:
+            return self._step_general(actions)
+        # the common case: every slot update is one fused launch, the boards that owe no ply are skipped
+        # inside the sampler, nothing else is computed on the host side of the ABI
+        obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
+        self._pick(0)                                   # BLACK agents whose game just ended: a new opponent
+        self._pick(1)                                   # fresh boards pick their opponent before it opens
+        self._opponent_actions(obs, legal, pending)     # replies (and openings of boards that just ended)
+        out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+        if self._any_white:                             # openings on the boards that ended on the reply
+            self._pick(1)
+            self._opening_actions()
+            self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+        self._pick(2)                                   # ended on the reply, agent BLACK
+        return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
+
+    def _step_general(self, actions):
+        """step() in torch ops: evaluation mode (the pool is walked in order: a running count over the boards)
+        and sample_board (fresh start positions between the rounds)"""
         self._draw_candidates()
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
         ended1 = self.vec.done != 0                    # ended on the agent's ply

@@ -632,3 +632,46 @@ def test_fused_masked_sampler_distribution_and_counter(hx):
     # odd shapes: one row, 169 columns
     one = sample_masked(torch.zeros((1, 169), device="cuda"), torch.ones((1, 169), dtype=torch.uint8, device="cuda"), gen, bad)
     assert 0 <= int(one[0]) < 169
+
+
+def test_pick_opponents_kernel_selects_the_right_boards(hx):
+    """hexvec_pick_opponents (setup_opponents, SelfplayWrapper.py:97-104, fused with the selection mask): which
+    boards get a new slot at each point of the vectorised step, the 80/20 split, untouched boards keep theirs"""
+    import ctypes as C
+    L = hx._lib.lib()
+    E, nbuf = 100000, 7
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    done = (torch.rand(E, generator=g, device=dev) < 0.5).to(torch.uint8)
+    pending = torch.randint(0, 3, (E,), generator=g, device=dev).to(torch.uint8)
+    white = (torch.rand(E, generator=g, device=dev) < 0.5).to(torch.uint8)
+    ended = torch.full((E,), 9, dtype=torch.uint8, device=dev)
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def pick(when):
+        slot = torch.full((E,), -5, dtype=torch.int64, device=dev)
+        hx._lib.check(L.hexvec_pick_opponents(p(slot), when, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8),
+                                              nbuf, C.c_uint64(11), p(state), None))
+        torch.cuda.synchronize()
+        return slot
+
+    s0 = pick(0)
+    assert torch.equal(ended, done)                                            # recorded for `when` = 2
+    sel0 = (done != 0) & (pending == 0)
+    assert bool((s0[~sel0] == -5).all()) and bool(((s0[sel0] >= -1) & (s0[sel0] < nbuf)).all())
+    assert 0.78 < float((s0[sel0] == -1).double().mean()) < 0.82               # 80 % the best model
+    members = s0[sel0][s0[sel0] >= 0]
+    f = torch.bincount(members, minlength=nbuf).double() / members.numel()
+    assert float((f - 1.0 / nbuf).abs().max()) < 0.02                          # the rest uniform over the pool
+    s1 = pick(1)
+    sel1 = pending == 2
+    assert bool((s1[~sel1] == -5).all()) and bool((s1[sel1] >= -1).all())
+    done2 = done | (torch.rand(E, generator=g, device=dev) < 0.3).to(torch.uint8)    # more boards ended since
+    done_saved, done = done, done2
+    s2 = pick(2)
+    sel2 = (done2 != 0) & (ended == 0) & (white == 0)
+    assert bool(sel2.any()) and bool((s2[~sel2] == -5).all()) and bool((s2[sel2] >= -1).all())
+    assert int(state[0]) == 3                                                  # one draw counter step per call
+    assert L.hexvec_pick_opponents(p(s2), 3, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8), nbuf,
+                                   C.c_uint64(11), p(state), None) == -1       # bad `when`
