@@ -81,8 +81,8 @@ def lib():
     L.hexvec_export_state.argtypes = [vp, vp, vp]
     L.hexvec_import_state.argtypes = [vp, vp, vp]
     L.hexvec_stream_synchronize.argtypes = [vp, vp]
-    L.hexvec_sample_masked.argtypes = [vp, C.c_longlong, vp, vp, i32, i32, u64, vp, vp, vp, vp]
-    L.hexvec_pick_opponents.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.c_float, i32, u64, vp, vp]
+    L.hexvec_sample_masked.argtypes = [vp, C.c_longlong, vp, vp, i32, i32, u64, u32, i32, vp, vp, vp, vp]
+    L.hexvec_pick_opponents.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.c_float, i32, u64, u32, i32, vp, vp]
     L.hexvec_board_size.argtypes = [vp]
     L.hexvec_num_envs.argtypes = [vp]
     L.hexvec_flags.argtypes = [vp]

@@ -33,7 +33,7 @@ __device__ __forceinline__ int dpp_i(int x, int sel) { return __float_as_int(dpp
 // state[0] = draw counter (state[1] unused)
 __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long long logits_row_stride,
                                                        const unsigned char *legal, const unsigned char *row_active,
-                                                       int rows, int cols, u32 seed_lo, u32 seed_hi,
+                                                       int rows, int cols, u32 seed_lo, u32 seed_hi, u32 salt,
                                                        const unsigned long long *state, int *actions,
                                                        unsigned long long *bad_rows)
 {
@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long
     const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
     const size_t base = (size_t)row * (size_t)cols;
     const size_t lbase = (size_t)row * (size_t)logits_row_stride; // stride 0: every board shares one logits row
-    const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U);
+    const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U) ^
+                     mix32(salt * 0x27D4EB2FU + 0x165667B1U);
     float best = -INFINITY;
     int besti = 0x7fffffff;
     bool bad = false;
@@ -101,7 +102,7 @@ __global__ void k_sample_bump(unsigned long long *state) { state[0] += 1ULL; }
 __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int when, const unsigned char *done,
                                                         const unsigned char *pending, unsigned char *ended,
                                                         const unsigned char *white, int rows, float prob_best,
-                                                        int pool_size, u32 seed_lo, u32 seed_hi,
+                                                        int pool_size, u32 seed_lo, u32 seed_hi, u32 salt,
                                                         const unsigned long long *state)
 {
     const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int whe
     }
     if (!sel) return;
     const unsigned long long ctr = state[0];
-    const u32 k = mix32(((u32)e + (u32)ctr * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ ((u32)(ctr >> 32) * 0xC2B2AE35U);
+    const u32 k = mix32(((u32)e + (u32)ctr * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ ((u32)(ctr >> 32) * 0xC2B2AE35U) ^
+                  mix32(salt * 0x27D4EB2FU + 0x165667B1U);
     const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const u32 member = __umulhi(mix32(k + 0x9E3779B9U), (u32)pool_size);
     slot[e] = u < prob_best ? -1LL : (long long)member;
@@ -130,9 +132,9 @@ static thread_local char g_serr[256] = "";
 extern "C" const char *hexvec_sample_last_error(void) { return g_serr; }
 
 extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_stride, const uint8_t *legal,
-                                    const uint8_t *row_active, int rows, int cols, uint64_t seed,
-                                    unsigned long long *state2, int32_t *actions, unsigned long long *bad_rows,
-                                    void *stream)
+                                    const uint8_t *row_active, int rows, int cols, uint64_t seed, uint32_t salt,
+                                    int advance, unsigned long long *state2, int32_t *actions,
+                                    unsigned long long *bad_rows, void *stream)
 {
     if (!legal || !actions || !state2 || rows < 0 || cols < 1) {
         snprintf(g_serr, sizeof(g_serr), "%s", "hexvec_sample_masked: legal / actions / state NULL or bad shape");
@@ -142,8 +144,8 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
     const long long threads = (long long)rows * 16;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, logits_row_stride,
-                       legal, row_active, rows, cols, (hv::u32)seed, (hv::u32)(seed >> 32), state2, actions, bad_rows);
-    hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
+                       legal, row_active, rows, cols, (hv::u32)seed, (hv::u32)(seed >> 32), salt, state2, actions, bad_rows);
+    if (advance) hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_serr, sizeof(g_serr), "hexvec_sample_masked: %s", hipGetErrorString(e));
@@ -154,7 +156,8 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
 
 extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const uint8_t *pending,
                                      uint8_t *ended, const uint8_t *white, int rows, float prob_best, int pool_size,
-                                     uint64_t seed, unsigned long long *state2, void *stream)
+                                     uint64_t seed, uint32_t salt, int advance, unsigned long long *state2,
+                                     void *stream)
 {
     const bool ok = slot && state2 && rows >= 0 && pool_size >= 1 && when >= 0 && when <= 2 &&
                     (when == 0 ? (done && pending && ended) : when == 1 ? pending != nullptr : (done && ended && white));
@@ -165,8 +168,8 @@ extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *don
     if (rows == 0) return HEXVEC_OK;
     hipLaunchKernelGGL(hv::k_pick_opponents, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (long long *)slot, when, done, pending, ended, white, rows, prob_best, pool_size, (hv::u32)seed,
-                       (hv::u32)(seed >> 32), state2);
-    hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
+                       (hv::u32)(seed >> 32), salt, state2);
+    if (advance) hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_serr, sizeof(g_serr), "hexvec_pick_opponents: %s", hipGetErrorString(e));

@@ -73,14 +73,16 @@ def sample_masked_torch(logits, legal, generator=None, bad_rows=None):
 _SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, reserved} of hexvec_sample_masked
 
 
-def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None, out=None):
+def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None, out=None, rng=None):
     """One categorical sample per row from softmax(logits) restricted to legal != 0 (logits None = uniform over
     the legal cells; a [1, C] logits row is shared by all boards), by the Gumbel-max trick argmax(logits + G):
     ONE libhexvec call (hexvec_sample_masked, include/hexvec.h), no device-side assertion, capturable in a
     hipGraph -- the draw counter lives on the device and advances with every call, also under graph replay.
     `generator` only names the random stream (its initial seed keys the counter hash); torch's own stream is
     not consumed.  row_active (uint8 / bool [rows], optional): boards with 0 get action 0 and are skipped.
-    out (int32 [rows], optional): where to write the actions.
+    out (int32 [rows], optional): where to write the actions.  rng = (state, seed, salt, advance), optional:
+    draw from the caller's counter instead (several calls of one step share it under different salts and
+    advance it once, with the last call).
 
     A DEGENERATE row -- no legal cell, or a NaN logit on a legal cell -- cannot be sampled; it yields
     action 0 (an illegal ply ends the episode with reward 0) and is COUNTED in `bad_rows` (int64 scalar on
@@ -103,16 +105,19 @@ def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None,
     if row_active is not None:
         ra = row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)
         ra = ra.contiguous()
-    key = (legal.device, id(generator))
-    st = _SAMPLER_STATE.get(key)
-    if st is None:
-        st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=legal.device)
-    seed = (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1)
+    if rng is not None:
+        st, seed, salt, advance = rng
+    else:
+        key = (legal.device, id(generator))
+        st = _SAMPLER_STATE.get(key)
+        if st is None:
+            st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=legal.device)
+        seed, salt, advance = (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1), 0, 1
     if out is None:
         out = torch.empty(rows, dtype=torch.int32, device=legal.device)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-    _lib.check(_lib.lib().hexvec_sample_masked(p(lo), stride, p(lg), p(ra), rows, cols, C.c_uint64(seed), p(st), p(out),
-                                               p(bad_rows),
+    _lib.check(_lib.lib().hexvec_sample_masked(p(lo), stride, p(lg), p(ra), rows, cols, C.c_uint64(seed), salt,
+                                               int(bool(advance)), p(st), p(out), p(bad_rows),
                                                C.c_void_p(torch.cuda.current_stream(legal.device).cuda_stream)))
     return out
 
@@ -139,8 +144,8 @@ class RandomLegalPolicy(_CountsBadRows):
         """policies with equal keys answer identically distributed and may share one batched call"""
         return ("random-legal", id(self.generator))
 
-    def choose_actions(self, obs, legal, row_active=None, out=None):
-        return sample_masked(None, legal, self.generator, self.bad_rows_counter(legal.device), row_active, out)
+    def choose_actions(self, obs, legal, row_active=None, out=None, rng=None):
+        return sample_masked(None, legal, self.generator, self.bad_rows_counter(legal.device), row_active, out, rng)
 
     def save_model(self, path):
         return None
@@ -195,13 +200,13 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         return z.masked_fill(legal == 0, float("-inf"))
 
     @torch.no_grad()
-    def choose_actions(self, obs, legal, row_active=None, out=None):
+    def choose_actions(self, obs, legal, row_active=None, out=None, rng=None):
         if self.deterministic:
             a = self.logits(obs, legal).argmax(1).to(torch.int32)
             return a if out is None else out.copy_(a)
         x = obs.reshape(obs.shape[0], -1).float()
         return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator,
-                             self.bad_rows_counter(legal.device), row_active, out)
+                             self.bad_rows_counter(legal.device), row_active, out, rng)
 
     def save_model(self, path):
         torch.save(self.state_dict(), path)
@@ -309,7 +314,11 @@ class VecSelfPlayEnv:
             groups.setdefault(key, (pol, []))[1].append(k)
         return groups
 
-    def _pick(self, when):
+    def _rng(self, salt, advance=False):
+        """the step's shared draw counter for the fused calls: distinct salts, advanced once (by the last)"""
+        return (self._pick_state, self._pick_seed, salt, advance)
+
+    def _pick(self, when, salt=0, advance=False):
         """setup_opponents (:97-104) for the boards that start a new episode at point `when` of the step, as
         ONE libhexvec launch (hexvec_pick_opponents: the selection mask and the 80/20 draw are fused); the
         evaluation walk (:92-96) needs a running count over the boards and keeps the torch spelling"""
@@ -319,10 +328,11 @@ class VecSelfPlayEnv:
         p = lambda t: C.c_void_p(t.data_ptr())
         _lib.check(_lib.lib().hexvec_pick_opponents(
             p(self.slot), when, p(v.done), p(v.pending), p(self._ended), p(self._white_u8), self.num_envs,
-            C.c_float(self.buffer.prob_best), len(self.buffer), C.c_uint64(self._pick_seed), p(self._pick_state),
+            C.c_float(self.buffer.prob_best), len(self.buffer), C.c_uint64(self._pick_seed), salt, int(advance),
+            p(self._pick_state),
             C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
-    def _opponent_actions(self, obs, legal, pending):
+    def _opponent_actions(self, obs, legal, pending, rng=None):
         """actions of every pending board's opponent: each distinct policy group is evaluated on the
         whole batch and its answers are kept where that policy is the opponent."""
         groups = self._groups()
@@ -330,7 +340,7 @@ class VecSelfPlayEnv:
         first = True
         for pol, slots in groups.values():
             if getattr(pol, "takes_row_active", False) and len(groups) == 1:      # the sampler skips the boards that owe no ply and writes in place
-                pol.choose_actions(obs, legal, row_active=pending, out=self._opp)
+                pol.choose_actions(obs, legal, row_active=pending, out=self._opp, rng=rng)
                 return
             if safe_legal is None:              # generic policies: boards that owe no ply look all-legal to them
                 safe_legal = torch.where(pending.view(-1, 1).bool(), legal, torch.ones_like(legal))
@@ -344,7 +354,7 @@ class VecSelfPlayEnv:
                 member |= self.slot == k
             torch.where(member, a, self._opp, out=self._opp)
 
-    def _opening_actions(self):
+    def _opening_actions(self, rng=None):
         """openings on EMPTY boards: every board that shares a policy has the same distribution, so a
         policy exposing logits() is evaluated on one empty board and sampled once per board"""
         n, E = self.board_size, self.num_envs
@@ -355,7 +365,7 @@ class VecSelfPlayEnv:
                 z = pol.logits(self._empty_board[:1], full[:1])     # one row, shared by every board
                 a = sample_masked(z, full, getattr(pol, "generator", None),
                                   pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter") else None,
-                                  out=self._opp if len(groups) == 1 else None)
+                                  out=self._opp if len(groups) == 1 else None, rng=rng if len(groups) == 1 else None)
                 if len(groups) == 1:
                     return
             else:
@@ -421,15 +431,16 @@ class VecSelfPlayEnv:
         # the common case: every slot update is one fused launch, the boards that owe no ply are skipped
         # inside the sampler, nothing else is computed on the host side of the ABI
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
-        self._pick(0)                                   # BLACK agents whose game just ended: a new opponent
-        self._pick(1)                                   # fresh boards pick their opponent before it opens
-        self._opponent_actions(obs, legal, pending)     # replies (and openings of boards that just ended)
+        # (all draws of the step share one device counter under salts 1..6; the last call advances it)
+        self._pick(0, salt=1)                           # BLACK agents whose game just ended: a new opponent
+        self._pick(1, salt=2)                           # fresh boards pick their opponent before it opens
+        self._opponent_actions(obs, legal, pending, rng=self._rng(3))   # replies (+ openings of boards that just ended)
         out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
         if self._any_white:                             # openings on the boards that ended on the reply
-            self._pick(1)
-            self._opening_actions()
+            self._pick(1, salt=4)
+            self._opening_actions(rng=self._rng(5))
             self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
-        self._pick(2)                                   # ended on the reply, agent BLACK
+        self._pick(2, salt=6, advance=True)             # ended on the reply, agent BLACK
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
     def _step_general(self, actions):

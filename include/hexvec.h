@@ -219,14 +219,15 @@ int hexvec_stream_synchronize(hexvec_t *h, void *stream);
  * share one row, e.g. the opening on an empty board), or NULL; legal uint8 [rows, cols]; row_active uint8 [rows]
  * or NULL: boards whose byte is 0 get action 0 and are neither sampled nor counted (the boards that owe no
  * opponent ply in this round); actions int32 [rows]; all device pointers.  Random numbers: Gumbel-max with a
- * counter hash of (seed, draw counter, row, column); state2 = two device uint64 words owned by the caller and
- * zeroed once {draw counter, reserved}: the call advances the counter on the device, so a captured graph draws
- * fresh numbers on every replay.  A row that cannot be sampled (no legal cell, NaN logit on a legal cell) yields
+ * counter hash of (seed, salt, draw counter, row, column); state2 = two device uint64 words owned by the caller
+ * and zeroed once {draw counter, reserved}.  advance != 0: the call advances the counter on the device (a
+ * one-thread kernel behind the sampling kernel), so a captured graph draws fresh numbers on every replay;
+ * several calls of one step may share a counter with different salts and advance it once, with the last.  A row that cannot be sampled (no legal cell, NaN logit on a legal cell) yields
  * action 0 and adds 1 to *bad_rows (device uint64, may be NULL).  Not the reference's Mersenne-Twister / torch
  * stream: the distribution is the same, the draws are not. */
 int hexvec_sample_masked(const float *logits, long long logits_row_stride, const uint8_t *legal,
-                         const uint8_t *row_active, int rows, int cols, uint64_t seed, unsigned long long *state2,
-                         int32_t *actions, unsigned long long *bad_rows, void *stream);
+                         const uint8_t *row_active, int rows, int cols, uint64_t seed, uint32_t salt, int advance,
+                         unsigned long long *state2, int32_t *actions, unsigned long long *bad_rows, void *stream);
 
 /* SelfPlayEnv.setup_opponents (SelfplayWrapper.py:97-104) for a batch of boards, outside evaluation: a board that
  * starts a new episode gets opponent slot -1 (the best model) with probability prob_best, else a uniformly drawn
@@ -238,10 +239,10 @@ int hexvec_sample_masked(const float *logits, long long logits_row_stride, const
  *      SelfplayWrapper.py:75, :79-80);
  *   2  after the opponent's replies: done[e] && !ended[e] && !white[e] (ended on the reply, agent BLACK).
  * slot int64 [rows], the byte arrays uint8 [rows], all on the device; random numbers as in hexvec_sample_masked
- * (counter hash; state2 = {draw counter, reserved}, advanced by the call). */
+ * (counter hash of seed, salt, draw counter, board; state2 = {draw counter, reserved}, advanced iff advance != 0). */
 int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const uint8_t *pending, uint8_t *ended,
                           const uint8_t *white, int rows, float prob_best, int pool_size, uint64_t seed,
-                          unsigned long long *state2, void *stream);
+                          uint32_t salt, int advance, unsigned long long *state2, void *stream);
 
 int hexvec_board_size(const hexvec_t *h);
 int hexvec_num_envs(const hexvec_t *h);

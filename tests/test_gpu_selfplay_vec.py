@@ -652,7 +652,7 @@ def test_pick_opponents_kernel_selects_the_right_boards(hx):
     def pick(when):
         slot = torch.full((E,), -5, dtype=torch.int64, device=dev)
         hx._lib.check(L.hexvec_pick_opponents(p(slot), when, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8),
-                                              nbuf, C.c_uint64(11), p(state), None))
+                                              nbuf, C.c_uint64(11), 0, 1, p(state), None))
         torch.cuda.synchronize()
         return slot
 
@@ -674,4 +674,14 @@ def test_pick_opponents_kernel_selects_the_right_boards(hx):
     assert bool(sel2.any()) and bool((s2[~sel2] == -5).all()) and bool((s2[sel2] >= -1).all())
     assert int(state[0]) == 3                                                  # one draw counter step per call
     assert L.hexvec_pick_opponents(p(s2), 3, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8), nbuf,
-                                   C.c_uint64(11), p(state), None) == -1       # bad `when`
+                                   C.c_uint64(11), 0, 1, p(state), None) == -1       # bad `when`
+    # several calls may share a counter under different salts and advance it once
+    before = int(state[0])
+    slot_a = torch.full((E,), -5, dtype=torch.int64, device=dev)
+    slot_b = torch.full((E,), -5, dtype=torch.int64, device=dev)
+    hx._lib.check(L.hexvec_pick_opponents(p(slot_a), 1, p(done), p(pending), p(ended), p(white), E, C.c_float(0.5), nbuf,
+                                          C.c_uint64(11), 1, 0, p(state), None))
+    hx._lib.check(L.hexvec_pick_opponents(p(slot_b), 1, p(done), p(pending), p(ended), p(white), E, C.c_float(0.5), nbuf,
+                                          C.c_uint64(11), 2, 1, p(state), None))
+    torch.cuda.synchronize()
+    assert int(state[0]) == before + 1 and float((slot_a[sel1] != slot_b[sel1]).double().mean()) > 0.3
