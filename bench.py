@@ -10,8 +10,8 @@ T = min(--chunk, K) steps per launch, every step's obs / mask / action /
 reward / done written to HBM); the host-stepped rate (one hexvec_step launch
 per step) is reported beside it.
 
-Timing: a fixed internal warm-up of rollout launches (>= 30 ms, the chip needs
-~10 ms of load to reach its clock; reported as warmup_internal_ms) precedes the
+Timing: a fixed internal warm-up of rollout launches (>= 150 ms, the chip needs
+tens of ms of load to settle its clock; reported as warmup_internal_ms) precedes the
 --warmup steps.  The K-step region is then repeated `timed_reps` times back to
 back inside ONE barrier + synchronize bracket; every repetition is timed with
 HIP events on the launch stream.  ms_per_step is the MEDIAN repetition (max
@@ -76,7 +76,7 @@ def main():
                     help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT); "
                          "auto = by the number of wavefronts the geometry gives (HexVecEnv rollout_layout='auto')")
     ap.add_argument("--reps", type=int, default=0, help="timed repetitions of the --steps region (0 = auto, >= 20)")
-    ap.add_argument("--warmup-internal-ms", type=float, default=30.0)
+    ap.add_argument("--warmup-internal-ms", type=float, default=150.0)
     args = ap.parse_args()
 
     import torch
