@@ -607,8 +607,20 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.pend = 0;
         L::fresh_regs(s, first);
     } else {
-        for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
-            reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(sblk)[i];
+        // The block image goes HBM -> LDS by LDS-DMA (no VGPR round trip): every 1 KB piece is in flight
+        // before the first one lands.  (A load / ds_write loop waits for each piece in turn: +2 us a launch.)
+        // The tail piece overlaps the one before it, so every instruction runs with all 64 lanes.
+        {
+            constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
+            static_assert(V16 >= 64 && L::LDS_BYTES % 16 == 0, "block image smaller than one piece");
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                const int at = (k * 64 + 64 <= V16 ? k * 64 : V16 - 64) * 16;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(sblk + at + lane * 16),
+                    (__attribute__((address_space(3))) void *)(lds + at), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
             s.E0[j] = rblk[j * 64 + lane];
