@@ -911,8 +911,25 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 
     emit_release();
     // state back to HBM
-    for (int i = lane; i < L::LDS_BYTES / 16; i += 64)
-        reinterpret_cast<uint4 *>(sblk)[i] = reinterpret_cast<const uint4 *>(lds)[i];
+    {   // eight 1 KB pieces per trip: the LDS reads of a trip are issued together, then its stores
+        constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
+#pragma unroll
+        for (int k0 = 0; k0 < PIECES; k0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < PIECES) {
+                    const int at = ((k0 + k) * 64 + 64 <= V16 ? (k0 + k) * 64 : V16 - 64) + lane;
+                    v[k] = reinterpret_cast<const uint4 *>(lds)[at];
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < PIECES) {
+                    const int at = ((k0 + k) * 64 + 64 <= V16 ? (k0 + k) * 64 : V16 - 64) + lane;
+                    reinterpret_cast<uint4 *>(sblk)[at] = v[k];
+                }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
         rblk[j * 64 + lane] = s.E0[j];
