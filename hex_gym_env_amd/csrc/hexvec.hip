@@ -56,6 +56,9 @@ struct DeviceGuard {
     } while (0)
 
 extern "C" const char *hexvec_last_error(void) { return g_err; }
+namespace hv {
+void set_error(const char *what, const char *detail) { snprintf(g_err, sizeof(g_err), "%s: %s", what, detail); }
+} // namespace hv
 extern "C" const char *hexvec_last_kernel(void) { return g_kernel; }
 
 namespace hv {

@@ -76,6 +76,9 @@ __device__ __forceinline__ u32 put_byte(u32 reg, int idx, u32 val, u32 lane)
 }
 
 
+// thread-local text behind hexvec_last_error(), shared by every translation unit (defined in hexvec.hip)
+void set_error(const char *what, const char *detail);
+
 // launchers, one per translation unit (so the kernel families compile in parallel)
 hipError_t wpb_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
 hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int enc, signed char *board,

@@ -1,0 +1,375 @@
+// hexvec_policy.hip -- the actor network of the self-play opponents (and of the agent) evaluated, masked and
+// sampled for a whole batch of boards in ONE launch: what OpponentPolicy.choose_action obtains from
+// model.predict(board, deterministic, action_masks=mask) (SelfplayWrapper.py:26-35) with SB3's default
+// MlpPolicy actor: flatten -> float -> Linear-Tanh-Linear-Tanh -> Linear -> logits -> masked categorical.
+// Every board may name its own network (its opponent slot, SelfplayWrapper.py:97-104): the boards are first
+// grouped by network with a counting sort (three small kernels) so that each workgroup serves 64 boards
+// of one network; the torch spelling evaluates every distinct pool member on the whole batch.
+//
+// Layout of the work: a workgroup = 64 boards x 4 wavefronts; lane = board; the wavefronts split the
+// OUTPUT neurons of each layer in chunks of 16.  Weights are wave-uniform, so they come through the
+// scalar cache (s_load_dwordx16 of a transposed, 64-byte-aligned row) and every lane runs fp32 FMAs
+// against its own activation, which the layers hand over through LDS as [neuron][lane] (conflict-free).
+// fp32 throughout (the logits must match the fp32 reference closely enough to give the same samples;
+// fp32 MFMA has the same peak as packed fp32 VALU on this chip, so the matrix cores buy nothing here).
+// Sampling is the Gumbel-max of hexvec_sample.hip with the same counter hash: the fused call returns the
+// actions hexvec_sample_masked returns on this kernel's logits.
+#include "hexvec_common.h"
+
+namespace hv {
+
+constexpr int POL_WAVES = 4;    // wavefronts per workgroup of k_mlp_actions
+constexpr int GRP_BLOCKS = 64;  // workgroups of the grouping kernels
+constexpr int GRP_THREADS = 256;
+constexpr int MAX_POLICIES = 256;
+
+struct MlpShape {
+    int cells, cp, h1, h2;
+    long long o_w1, o_b1, o_w2, o_b2, o_w3, o_b3, stride; // offsets in floats, all multiples of 16
+};
+__host__ __device__ inline MlpShape mlp_shape(int cells, int h1, int h2)
+{
+    MlpShape s;
+    s.cells = cells;
+    s.cp = (cells + 15) & ~15;
+    s.h1 = h1;
+    s.h2 = h2;
+    s.o_w1 = 0;
+    s.o_b1 = s.o_w1 + (long long)cells * h1;
+    s.o_w2 = s.o_b1 + h1;
+    s.o_b2 = s.o_w2 + (long long)h1 * h2;
+    s.o_w3 = s.o_b2 + h2;
+    s.o_b3 = s.o_w3 + (long long)h2 * s.cp;
+    s.stride = s.o_b3 + s.cp;
+    return s;
+}
+
+struct MlpArgs {
+    const signed char *obs;
+    const unsigned char *legal;
+    const unsigned char *row_active;
+    const long long *slot;
+    const int *policy_of_slot;
+    int slot_bias, n_slots, n_policies;
+    int rows;
+    MlpShape sh;
+    const float *weights;
+    int deterministic;
+    u32 seed_lo, seed_hi, salt;
+    const unsigned long long *state;
+    int *actions;
+    float *logits_out;
+    unsigned long long *bad_rows;
+    const int *order;  // grouped launches: board of every position (-1 = hole), else NULL
+    const int *ntiles; // grouped launches: tiles in use
+};
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1): |error| < 2e-7 absolute over the whole range (saturates cleanly at +-1)
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float t = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
+// the network of a board: its slot (+ bias) looked up in the pool's slot -> network table
+__device__ __forceinline__ int policy_key(const MlpArgs &a, int r)
+{
+    if (!a.slot) return 0;
+    long long s = a.slot[r] + (long long)a.slot_bias;
+    s = s < 0 ? 0 : (s >= a.n_slots ? a.n_slots - 1 : s);
+    int p = a.policy_of_slot ? a.policy_of_slot[s] : (int)s;
+    return p < 0 ? 0 : (p >= a.n_policies ? a.n_policies - 1 : p);
+}
+
+// acc[k] = bias[q*16+k] + sum_i wt[i][q*16+k] * x_i for this lane's board; X(i) fetches x_i
+template <typename X>
+__device__ __forceinline__ void dense16(const float *__restrict__ wt, const float *__restrict__ bias, int K, int OP, int q,
+                                        X x_of, float (&acc)[16])
+{
+    const float *__restrict__ w = wt + q * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = bias[q * 16 + k];
+#pragma unroll 4
+    for (int i = 0; i < K; ++i) {
+        const float x = x_of(i);
+        const float *__restrict__ wr = w + (size_t)i * (size_t)OP;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = __builtin_fmaf(wr[k], x, acc[k]);
+    }
+}
+
+__global__ __launch_bounds__(64 * POL_WAVES) void k_mlp_actions(MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = rfl((int)threadIdx.x >> 6);
+    const int tile = (int)blockIdx.x;
+    if (a.ntiles && tile >= *a.ntiles) return;
+    const int cells = a.sh.cells, cp = a.sh.cp, h1 = a.sh.h1, h2 = a.sh.h2;
+
+    const int pos = tile * 64 + lane;
+    int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
+    if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) { // nobody asked for this board's action
+        if (wave == 0) a.actions[r] = 0;
+        r = -1;
+    }
+    const u64 vmask = __ballot(r >= 0); // the same in every wavefront of the workgroup
+    if (vmask == 0) return;
+    const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
+    const int p = rfl(policy_key(a, r0)); // grouped launches: one network per tile
+    const float *__restrict__ wp = a.weights + (size_t)p * (size_t)a.sh.stride;
+
+    // LDS: obs bytes [64][cells] | legal bytes [64][cells] | hA [h1][64] | hB [h2][64] | reduction [W][64] x 3 | rows [64]
+    const int img = (64 * cells + 15) & ~15;
+    signed char *obs_b = reinterpret_cast<signed char *>(smem);
+    unsigned char *legal_b = smem + img;
+    float *hA = reinterpret_cast<float *>(smem + 2 * img);
+    float *hB = hA + h1 * 64;
+    float *red_v = hB + h2 * 64;
+    int *red_i = reinterpret_cast<int *>(red_v + POL_WAVES * 64);
+    int *red_b = red_i + POL_WAVES * 64;
+    int *rows_l = red_b + POL_WAVES * 64;
+
+    if (wave == 0) rows_l[lane] = r;
+    __syncthreads();
+    // the tile's observation and mask rows: wavefront w copies boards w, w+4, ... (a row is contiguous)
+    for (int b = wave; b < 64; b += POL_WAVES) {
+        const int src = rows_l[b];
+        for (int c = lane; c < cells; c += 64) {
+            obs_b[b * cells + c] = src >= 0 ? a.obs[(size_t)src * cells + c] : (signed char)0;
+            legal_b[b * cells + c] = src >= 0 ? a.legal[(size_t)src * cells + c] : (unsigned char)0;
+        }
+    }
+    __syncthreads();
+
+    float acc[16];
+    // layer 1: cells -> h1, tanh
+    for (int q = wave; q < h1 / 16; q += POL_WAVES) {
+        dense16(wp + a.sh.o_w1, wp + a.sh.o_b1, cells, h1, q,
+                [&](int i) { return (float)(int)obs_b[lane * cells + i]; }, acc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hA[(q * 16 + k) * 64 + lane] = tanh_fast(acc[k]);
+    }
+    __syncthreads();
+    // layer 2: h1 -> h2, tanh
+    for (int q = wave; q < h2 / 16; q += POL_WAVES) {
+        dense16(wp + a.sh.o_w2, wp + a.sh.o_b2, h1, h2, q, [&](int i) { return hA[i * 64 + lane]; }, acc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hB[(q * 16 + k) * 64 + lane] = tanh_fast(acc[k]);
+    }
+    __syncthreads();
+    // layer 3: h2 -> logits; masked Gumbel-max (or argmax) over this wavefront's cells on the fly
+    const unsigned long long ctr = a.state ? a.state[0] : 0ULL;
+    const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
+    const u32 rkey = mix32(((u32)r + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi ^ (c_hi * 0xC2B2AE35U) ^
+                     mix32(a.salt * 0x27D4EB2FU + 0x165667B1U); // = k_sample_masked's row key
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    bool bad = false;
+    for (int q = wave; q < cp / 16; q += POL_WAVES) {
+        dense16(wp + a.sh.o_w3, wp + a.sh.o_b3, h2, cp, q, [&](int i) { return hB[i * 64 + lane]; }, acc);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = q * 16 + k;
+            if (c < cells) {
+                const float z = acc[k];
+                if (a.logits_out && r >= 0) a.logits_out[(size_t)r * cells + c] = z;
+                float v = z;
+                if (!a.deterministic) {
+                    const u32 h = mix32(rkey + (u32)c * 0x9E3779B9U);
+                    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); // in (0, 1)
+                    v = z - __logf(-__logf(u));
+                }
+                const bool on = legal_b[lane * cells + c] != 0;
+                bad = bad || (on && z != z);
+                if (on && v > best) {
+                    best = v;
+                    besti = c;
+                }
+            }
+        }
+    }
+    red_v[wave * 64 + lane] = best;
+    red_i[wave * 64 + lane] = besti;
+    red_b[wave * 64 + lane] = bad ? 1 : 0;
+    __syncthreads();
+    if (wave == 0) {
+        best = red_v[lane];
+        besti = red_i[lane];
+        bad = red_b[lane] != 0;
+#pragma unroll
+        for (int w = 1; w < POL_WAVES; ++w) {
+            const float ob = red_v[w * 64 + lane];
+            const int oi = red_i[w * 64 + lane];
+            const bool take = ob > best || (ob == best && oi < besti); // ties go to the lower cell
+            best = take ? ob : best;
+            besti = take ? oi : besti;
+            bad = bad || red_b[w * 64 + lane] != 0;
+        }
+        const bool degenerate = r >= 0 && (bad || !(best > -INFINITY));
+        if (r >= 0) a.actions[r] = degenerate ? 0 : besti;
+        const u64 dm = __ballot(degenerate);
+        if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
+    }
+}
+
+// advances the draw counter behind the sampling workgroups (see k_sample_bump, hexvec_sample.hip)
+__global__ void k_policy_bump(unsigned long long *state) { state[0] += 1ULL; }
+
+// ---- grouping the boards by network: counting sort, three launches, no atomics on global memory ----
+// scratch (ints): [0] tiles in use | [16 ..) per-workgroup bucket counts / offsets [GRP_BLOCKS][n_policies] |
+// then the order: board of every position, buckets padded to whole tiles with -1
+__device__ __forceinline__ int grp_chunk(int rows) { return (rows + GRP_BLOCKS - 1) / GRP_BLOCKS; }
+
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_count(MlpArgs a, int *counts)
+{
+    __shared__ int h[MAX_POLICIES];
+    for (int k = (int)threadIdx.x; k < a.n_policies; k += GRP_THREADS) h[k] = 0;
+    __syncthreads();
+    const int chunk = grp_chunk(a.rows), lo = (int)blockIdx.x * chunk, hi = min(a.rows, lo + chunk);
+    for (int r = lo + (int)threadIdx.x; r < hi; r += GRP_THREADS)
+        if (!a.row_active || a.row_active[r] != 0) atomicAdd(&h[policy_key(a, r)], 1);
+    __syncthreads();
+    for (int k = (int)threadIdx.x; k < a.n_policies; k += GRP_THREADS) counts[(int)blockIdx.x * a.n_policies + k] = h[k];
+}
+
+__global__ __launch_bounds__(MAX_POLICIES) void k_grp_scan(int n_policies, int *ntiles, int *counts, int *order)
+{
+    __shared__ int tot[MAX_POLICIES], start[MAX_POLICIES];
+    const int k = (int)threadIdx.x;
+    int total = 0;
+    if (k < n_policies)
+        for (int g = 0; g < GRP_BLOCKS; ++g) { // exclusive offsets of the workgroups inside bucket k
+            const int c = counts[g * n_policies + k];
+            counts[g * n_policies + k] = total;
+            total += c;
+        }
+    tot[k] = total;
+    __syncthreads();
+    if (k == 0) {
+        int run = 0;
+        for (int j = 0; j < n_policies; ++j) { // buckets start on tile boundaries
+            start[j] = run;
+            run += (tot[j] + 63) & ~63;
+        }
+        *ntiles = run >> 6;
+    }
+    __syncthreads();
+    if (k < n_policies) {
+        for (int g = 0; g < GRP_BLOCKS; ++g) counts[g * n_policies + k] += start[k];
+        for (int pos = start[k] + total; pos < start[k] + ((total + 63) & ~63); ++pos) order[pos] = -1;
+    }
+}
+
+__global__ __launch_bounds__(GRP_THREADS) void k_grp_scatter(MlpArgs a, const int *offsets, int *order)
+{
+    __shared__ int base[MAX_POLICIES], cnt[MAX_POLICIES];
+    for (int k = (int)threadIdx.x; k < a.n_policies; k += GRP_THREADS) {
+        base[k] = offsets[(int)blockIdx.x * a.n_policies + k];
+        cnt[k] = 0;
+    }
+    __syncthreads();
+    const int chunk = grp_chunk(a.rows), lo = (int)blockIdx.x * chunk, hi = min(a.rows, lo + chunk);
+    for (int r = lo + (int)threadIdx.x; r < hi; r += GRP_THREADS) {
+        if (!a.row_active || a.row_active[r] != 0) {
+            const int key = policy_key(a, r);
+            order[base[key] + atomicAdd(&cnt[key], 1)] = r;
+        } else {
+            a.actions[r] = 0; // nobody asked for this board's action
+        }
+    }
+}
+
+} // namespace hv
+
+extern "C" size_t hexvec_mlp_weights_floats(int cells, int h1, int h2)
+{
+    if (cells < 1 || h1 < 16 || h2 < 16 || (h1 & 15) || (h2 & 15)) return 0;
+    return (size_t)hv::mlp_shape(cells, h1, h2).stride;
+}
+
+extern "C" size_t hexvec_mlp_scratch_bytes(int rows, int n_policies)
+{
+    if (rows < 0 || n_policies < 1 || n_policies > hv::MAX_POLICIES) return 0;
+    return sizeof(int) * (16 + (size_t)hv::GRP_BLOCKS * n_policies + (size_t)rows + 64 * (size_t)n_policies + 64);
+}
+
+extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const uint8_t *row_active, const int64_t *slot,
+                                  int slot_bias, const int32_t *policy_of_slot, int n_slots, int rows, int cells,
+                                  const float *weights, int n_policies, int h1, int h2, int deterministic, uint64_t seed,
+                                  uint32_t salt, int advance, unsigned long long *state2, int32_t *actions,
+                                  float *logits_out, unsigned long long *bad_rows, void *scratch, size_t scratch_bytes,
+                                  void *stream)
+{
+    using namespace hv;
+    auto fail = [&](const char *m) {
+        set_error("hexvec_mlp_actions", m);
+        return HEXVEC_E_ARG;
+    };
+    if (!obs || !legal || !weights || !actions || rows < 0) return fail("obs / legal / weights / actions NULL or rows < 0");
+    if (cells < 1 || cells > HEXVEC_MAX_BOARD * HEXVEC_MAX_BOARD) return fail("cells out of range");
+    if (h1 < 16 || h2 < 16 || (h1 & 15) || (h2 & 15) || h1 > 256 || h2 > 256)
+        return fail("hidden widths must be multiples of 16 in [16, 256]");
+    if (n_policies < 1 || n_policies > MAX_POLICIES) return fail("n_policies out of range");
+    if (!deterministic && !state2) return fail("sampling needs the draw counter (state2)");
+    if (((uintptr_t)weights & 63) != 0) return fail("weights must be 64-byte aligned");
+    const bool grouped = slot != nullptr && n_policies > 1;
+    if (slot && n_slots < 1) return fail("n_slots < 1");
+    if (grouped && (!scratch || scratch_bytes < hexvec_mlp_scratch_bytes(rows, n_policies)))
+        return fail("scratch missing or smaller than hexvec_mlp_scratch_bytes()");
+    if (rows == 0) return HEXVEC_OK;
+
+    hipStream_t st = (hipStream_t)stream;
+    MlpArgs a;
+    a.obs = (const signed char *)obs;
+    a.legal = legal;
+    a.row_active = row_active;
+    a.slot = (const long long *)slot;
+    a.policy_of_slot = policy_of_slot;
+    a.slot_bias = slot_bias;
+    a.n_slots = slot ? n_slots : 1;
+    a.n_policies = n_policies;
+    a.rows = rows;
+    a.sh = mlp_shape(cells, h1, h2);
+    a.weights = weights;
+    a.deterministic = deterministic;
+    a.seed_lo = (u32)seed;
+    a.seed_hi = (u32)(seed >> 32);
+    a.salt = salt;
+    a.state = state2;
+    a.actions = actions;
+    a.logits_out = logits_out;
+    a.bad_rows = bad_rows;
+    a.order = nullptr;
+    a.ntiles = nullptr;
+    unsigned tiles = (unsigned)((rows + 63) / 64);
+    if (grouped) {
+        int *hdr = (int *)scratch, *counts = hdr + 16, *order = counts + (size_t)GRP_BLOCKS * n_policies;
+        hipLaunchKernelGGL(k_grp_count, dim3(GRP_BLOCKS), dim3(GRP_THREADS), 0, st, a, counts);
+        hipLaunchKernelGGL(k_grp_scan, dim3(1), dim3(MAX_POLICIES), 0, st, n_policies, hdr, counts, order);
+        hipLaunchKernelGGL(k_grp_scatter, dim3(GRP_BLOCKS), dim3(GRP_THREADS), 0, st, a, (const int *)counts, order);
+        a.order = order;
+        a.ntiles = hdr;
+        a.row_active = nullptr; // inactive boards are not in the order
+        tiles += (unsigned)n_policies;
+    }
+    const int img = (64 * cells + 15) & ~15;
+    const size_t lds = 2 * (size_t)img + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * POL_WAVES + 1);
+    static thread_local size_t lds_allowed = 0;
+    if (lds > lds_allowed) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_mlp_actions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_error("hexvec_mlp_actions", hipGetErrorString(e));
+            return HEXVEC_E_HIP;
+        }
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(k_mlp_actions, dim3(tiles), dim3(64 * POL_WAVES), lds, st, a);
+    if (advance && state2) hipLaunchKernelGGL(k_policy_bump, dim3(1), dim3(1), 0, st, state2);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("hexvec_mlp_actions", hipGetErrorString(e));
+        return HEXVEC_E_HIP;
+    }
+    return HEXVEC_OK;
+}

@@ -128,8 +128,6 @@ __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int whe
 
 } // namespace hv
 
-static thread_local char g_serr[256] = "";
-extern "C" const char *hexvec_sample_last_error(void) { return g_serr; }
 
 extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_stride, const uint8_t *legal,
                                     const uint8_t *row_active, int rows, int cols, uint64_t seed, uint32_t salt,
@@ -137,7 +135,7 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
                                     unsigned long long *bad_rows, void *stream)
 {
     if (!legal || !actions || !state2 || rows < 0 || cols < 1) {
-        snprintf(g_serr, sizeof(g_serr), "%s", "hexvec_sample_masked: legal / actions / state NULL or bad shape");
+        hv::set_error("hexvec_sample_masked", "legal / actions / state NULL or bad shape");
         return HEXVEC_E_ARG;
     }
     if (rows == 0) return HEXVEC_OK;
@@ -148,7 +146,7 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
     if (advance) hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        snprintf(g_serr, sizeof(g_serr), "hexvec_sample_masked: %s", hipGetErrorString(e));
+        hv::set_error("hexvec_sample_masked", hipGetErrorString(e));
         return HEXVEC_E_HIP;
     }
     return HEXVEC_OK;
@@ -162,7 +160,7 @@ extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *don
     const bool ok = slot && state2 && rows >= 0 && pool_size >= 1 && when >= 0 && when <= 2 &&
                     (when == 0 ? (done && pending && ended) : when == 1 ? pending != nullptr : (done && ended && white));
     if (!ok) {
-        snprintf(g_serr, sizeof(g_serr), "%s", "hexvec_pick_opponents: NULL argument or bad `when` / shape");
+        hv::set_error("hexvec_pick_opponents", "NULL argument or bad `when` / shape");
         return HEXVEC_E_ARG;
     }
     if (rows == 0) return HEXVEC_OK;
@@ -172,7 +170,7 @@ extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *don
     if (advance) hipLaunchKernelGGL(hv::k_sample_bump, dim3(1), dim3(1), 0, (hipStream_t)stream, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        snprintf(g_serr, sizeof(g_serr), "hexvec_pick_opponents: %s", hipGetErrorString(e));
+        hv::set_error("hexvec_pick_opponents", hipGetErrorString(e));
         return HEXVEC_E_HIP;
     }
     return HEXVEC_OK;

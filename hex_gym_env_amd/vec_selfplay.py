@@ -105,20 +105,68 @@ def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None,
     if row_active is not None:
         ra = row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)
         ra = ra.contiguous()
-    if rng is not None:
-        st, seed, salt, advance = rng
-    else:
-        key = (legal.device, id(generator))
-        st = _SAMPLER_STATE.get(key)
-        if st is None:
-            st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=legal.device)
-        seed, salt, advance = (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1), 0, 1
+    st, seed, salt, advance = _draw_stream(legal.device, generator, rng)
     if out is None:
         out = torch.empty(rows, dtype=torch.int32, device=legal.device)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     _lib.check(_lib.lib().hexvec_sample_masked(p(lo), stride, p(lg), p(ra), rows, cols, C.c_uint64(seed), salt,
                                                int(bool(advance)), p(st), p(out), p(bad_rows),
                                                C.c_void_p(torch.cuda.current_stream(legal.device).cuda_stream)))
+    return out
+
+
+def _draw_stream(device, generator, rng):
+    """(state, seed, salt, advance) of a sampling call: the caller's counter, or the one named by `generator`"""
+    if rng is not None:
+        return rng
+    key = (device, id(generator))
+    st = _SAMPLER_STATE.get(key)
+    if st is None:
+        st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=device)
+    return st, (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1), 0, 1
+
+
+def mlp_actions(weights, cells, h1, h2, obs, legal, row_active=None, slot=None, slot_bias=0, policy_of_slot=None,
+                deterministic=False, generator=None, rng=None, out=None, logits_out=None, bad_rows=None, scratch=None):
+    """Actor forward + mask + sample for a batch of boards as ONE libhexvec call (hexvec_mlp_actions,
+    include/hexvec.h): weights float32 [n_policies, hexvec_mlp_weights_floats] in the packed layout
+    (MlpActorPolicy.pack_into); slot int64 [rows] (+ slot_bias, through policy_of_slot int32 if given) names each
+    board's network; with several networks the boards are grouped by network on the device (scratch: uint8 tensor
+    of hexvec_mlp_scratch_bytes, allocated here if None).  The draws are sample_masked()'s.  Returns int32 [rows]."""
+    import ctypes as C
+    from . import _lib
+    if not legal.is_cuda:
+        raise RuntimeError("mlp_actions runs on the GPU only (libhexvec has no CPU path)")
+    rows = legal.shape[0]
+    ob = obs.reshape(rows, -1)
+    ob = ob if ob.dtype == torch.int8 and ob.is_contiguous() else ob.to(torch.int8).contiguous()
+    lg = legal if legal.dtype == torch.uint8 and legal.is_contiguous() else legal.to(torch.uint8).contiguous()
+    if ob.shape[1] != cells or lg.shape[1] != cells:
+        raise ValueError("obs / legal do not have %d cells per board" % cells)
+    ra = None
+    if row_active is not None:
+        ra = (row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)).contiguous()
+    weights = weights.view(-1, weights.shape[-1])
+    n_pol = weights.shape[0]
+    L = _lib.lib()
+    if weights.dtype != torch.float32 or not weights.is_contiguous() or weights.shape[1] != L.hexvec_mlp_weights_floats(cells, h1, h2):
+        raise ValueError("weights are not float32 [n_policies, hexvec_mlp_weights_floats(cells, h1, h2)]")
+    n_slots = 1
+    if slot is not None:
+        if slot.dtype != torch.long or not slot.is_contiguous():
+            raise ValueError("slot must be a contiguous int64 tensor")
+        n_slots = n_pol if policy_of_slot is None else policy_of_slot.numel()
+        if n_pol > 1 and scratch is None:
+            scratch = torch.empty(L.hexvec_mlp_scratch_bytes(rows, n_pol), dtype=torch.uint8, device=legal.device)
+    st, seed, salt, advance = _draw_stream(legal.device, generator, rng)
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int32, device=legal.device)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _lib.check(L.hexvec_mlp_actions(p(ob), p(lg), p(ra), p(slot), slot_bias, p(policy_of_slot), n_slots, rows, cells,
+                                    p(weights), n_pol, h1, h2, int(bool(deterministic)), C.c_uint64(seed), salt,
+                                    int(bool(advance)), p(st), p(out), p(logits_out), p(bad_rows), p(scratch),
+                                    0 if scratch is None else scratch.numel(),
+                                    C.c_void_p(torch.cuda.current_stream(legal.device).cuda_stream)))
     return out
 
 
@@ -166,6 +214,10 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         self.action_net = torch.nn.Linear(dims[-1], n_cells)
         self.deterministic = deterministic
         self.generator = generator
+        self.n_cells, self.hidden = n_cells, tuple(hidden)
+        # the fused libhexvec call serves the SB3-default shape family; anything else keeps the torch spelling
+        self.fusable = len(self.hidden) == 2 and all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
+        self._packed = self._packed_version = None
 
     @classmethod
     def from_state_dict(cls, sd, **kw):
@@ -199,8 +251,51 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         z = self.action_net(self.policy_net(x))
         return z.masked_fill(legal == 0, float("-inf"))
 
+    # -- the fused path: weights packed for hexvec_mlp_actions (include/hexvec.h) --
+    def weights_version(self):
+        """changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to())"""
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed_floats(self):
+        from . import _lib
+        return int(_lib.lib().hexvec_mlp_weights_floats(self.n_cells, *self.hidden))
+
+    @torch.no_grad()
+    def pack_into(self, dst):
+        """write this network into dst (float32 [packed_floats()]) in the library's layout: every matrix
+        transposed to [input][output], the output layer padded to a multiple of 16 columns"""
+        cells, (h1, h2) = self.n_cells, self.hidden
+        cp = (cells + 15) // 16 * 16
+        l1, l2 = [m for m in self.policy_net if isinstance(m, torch.nn.Linear)]
+        dst.zero_()
+        o = 0
+        for w, b, cols in ((l1.weight, l1.bias, h1), (l2.weight, l2.bias, h2), (self.action_net.weight, self.action_net.bias, cp)):
+            k, n = w.shape[1], w.shape[0]
+            dst[o:o + k * cols].view(k, cols)[:, :n].copy_(w.t())
+            o += k * cols
+            dst[o:o + n].copy_(b)
+            o += cols
+        return dst
+
+    def packed(self):
+        """the packed weights on the parameters' device, re-packed when the parameters changed"""
+        v = self.weights_version()
+        if self._packed is None or self._packed.device != self.action_net.weight.device:
+            self._packed = torch.empty(self.packed_floats(), dtype=torch.float32, device=self.action_net.weight.device)
+            self._packed_version = None
+        if self._packed_version != v:
+            self.pack_into(self._packed)
+            self._packed_version = v
+        return self._packed
+
+    sync_weights = packed        # call before replaying a captured graph that contains choose_actions
+
     @torch.no_grad()
     def choose_actions(self, obs, legal, row_active=None, out=None, rng=None):
+        if self.fusable:         # forward + mask + sample (or arg-max): one launch
+            return mlp_actions(self.packed(), self.n_cells, self.hidden[0], self.hidden[1], obs, legal, row_active,
+                               deterministic=self.deterministic, generator=self.generator, rng=rng, out=out,
+                               bad_rows=self.bad_rows_counter(legal.device))
         if self.deterministic:
             a = self.logits(obs, legal).argmax(1).to(torch.int32)
             return a if out is None else out.copy_(a)
@@ -238,6 +333,51 @@ def as_policy(model):
     if hasattr(model, "predict"):
         return PredictAdapter(model)
     raise TypeError("an opponent needs choose_actions(obs, legal) or predict(obs, deterministic, action_masks)")
+
+
+class _PoolTable:
+    """The pool's actor networks as ONE weights table for hexvec_mlp_actions: entry 0 of policy_of_slot is the best
+    model, entry k + 1 pool member k; slots holding the same policy object share a network.  sync() re-packs the
+    networks whose parameters changed (the reference keeps live models in the pool, SelfplayWrapper.py:125-136)."""
+
+    def __init__(self, by_slot, device, num_envs):
+        from . import _lib
+        uniq, pos = {}, []
+        for pol in by_slot:
+            pos.append(uniq.setdefault(id(pol), (len(uniq), pol))[0])
+        self.policies = [pol for _, pol in sorted(uniq.values(), key=lambda t: t[0])]
+        first = self.policies[0]
+        self.cells, self.hidden, self.deterministic = first.n_cells, first.hidden, bool(first.deterministic)
+        self.table = torch.empty((len(self.policies), first.packed_floats()), dtype=torch.float32, device=device)
+        self.policy_of_slot = torch.tensor(pos, dtype=torch.int32, device=device)
+        self.versions = [None] * len(self.policies)
+        self.scratch = None
+        if len(self.policies) > 1:
+            self.scratch = torch.empty(_lib.lib().hexvec_mlp_scratch_bytes(num_envs, len(self.policies)),
+                                       dtype=torch.uint8, device=device)
+        self.bad_rows = first.bad_rows_counter(device)
+        self.sync()
+
+    @staticmethod
+    def fits(by_slot, device):
+        first = by_slot[0]
+        return all(isinstance(p, MlpActorPolicy) and p.fusable and p.n_cells == first.n_cells
+                   and p.hidden == first.hidden and bool(p.deterministic) == bool(first.deterministic)
+                   and p.action_net.weight.device == torch.device(device) for p in by_slot)
+
+    def sync(self):
+        for u, pol in enumerate(self.policies):
+            v = pol.weights_version()
+            if v != self.versions[u]:
+                pol.pack_into(self.table[u])
+                self.versions[u] = v
+
+    def actions(self, obs, legal, slot, row_active, out, generator, rng):
+        self.sync()
+        return mlp_actions(self.table, self.cells, self.hidden[0], self.hidden[1], obs, legal, row_active,
+                           slot=slot, slot_bias=1, policy_of_slot=self.policy_of_slot,
+                           deterministic=self.deterministic, generator=generator, rng=rng, out=out,
+                           bad_rows=self.bad_rows, scratch=self.scratch)
 
 
 class VecSelfPlayEnv:
@@ -314,6 +454,16 @@ class VecSelfPlayEnv:
             groups.setdefault(key, (pol, []))[1].append(k)
         return groups
 
+    def _pool_table(self):
+        """the pool as one weights table if every member is an MlpActorPolicy of one shape on this device
+        (then an opponent round is ONE policy launch whatever the pool holds), else None"""
+        key = tuple(id(self.buffer.policy(k)) for k in range(-1, len(self.buffer)))
+        if getattr(self, "_table_key", None) != key:
+            by_slot = [self.buffer.policy(k) for k in range(-1, len(self.buffer))]
+            self._table = _PoolTable(by_slot, self.device, self.num_envs) if _PoolTable.fits(by_slot, self.device) else None
+            self._table_key = key
+        return self._table
+
     def _rng(self, salt, advance=False):
         """the step's shared draw counter for the fused calls: distinct salts, advanced once (by the last)"""
         return (self._pick_state, self._pick_seed, salt, advance)
@@ -335,6 +485,10 @@ class VecSelfPlayEnv:
     def _opponent_actions(self, obs, legal, pending, rng=None):
         """actions of every pending board's opponent: each distinct policy group is evaluated on the
         whole batch and its answers are kept where that policy is the opponent."""
+        tab = self._pool_table()
+        if tab is not None:
+            tab.actions(obs, legal, self.slot, pending, self._opp, self._gen, rng)
+            return
         groups = self._groups()
         safe_legal = None
         first = True
@@ -354,20 +508,28 @@ class VecSelfPlayEnv:
                 member |= self.slot == k
             torch.where(member, a, self._opp, out=self._opp)
 
-    def _opening_actions(self, rng=None):
+    def _opening_actions(self, rng=None, pending=None):
         """openings on EMPTY boards: every board that shares a policy has the same distribution, so a
-        policy exposing logits() is evaluated on one empty board and sampled once per board"""
+        policy exposing logits() is evaluated on one empty board and sampled once per board; a pool of several
+        actor networks is one fused launch over the boards that owe an opening (`pending`, all if None)"""
         n, E = self.board_size, self.num_envs
+        tab = self._pool_table()
+        if tab is not None and len(tab.policies) > 1:
+            tab.actions(self._empty_board, self._all_legal, self.slot, pending, self._opp, self._gen, rng)
+            return
         groups = self._groups()
         full = self._all_legal
         for pol, slots in groups.values():
             if hasattr(pol, "logits"):
                 z = pol.logits(self._empty_board[:1], full[:1])     # one row, shared by every board
-                a = sample_masked(z, full, getattr(pol, "generator", None),
-                                  pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter") else None,
-                                  out=self._opp if len(groups) == 1 else None, rng=rng if len(groups) == 1 else None)
-                if len(groups) == 1:
-                    return
+                if getattr(pol, "deterministic", False):
+                    a = z.argmax(1).to(torch.int32).expand(E)
+                else:
+                    a = sample_masked(z, full, getattr(pol, "generator", None),
+                                      pol.bad_rows_counter(self.device) if hasattr(pol, "bad_rows_counter") else None,
+                                      out=self._opp if len(groups) == 1 else None, rng=rng if len(groups) == 1 else None)
+                    if len(groups) == 1:
+                        return
             else:
                 a = pol.choose_actions(self._empty_board, full).to(torch.int32)
             if len(groups) == 1:
@@ -438,7 +600,7 @@ class VecSelfPlayEnv:
         out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
         if self._any_white:                             # openings on the boards that ended on the reply
             self._pick(1, salt=4)
-            self._opening_actions(rng=self._rng(5))
+            self._opening_actions(rng=self._rng(5), pending=self.vec.pending)
             self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
         self._pick(2, salt=6, advance=True)             # ended on the reply, agent BLACK
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
@@ -506,9 +668,17 @@ class VecSelfPlayEnv:
 
         capture()
 
+        def sync_weights():      # packed weight tables are static buffers of the graph: refresh them on the host side
+            tab = self._pool_table()
+            if tab is not None:
+                tab.sync()
+            if hasattr(agent_policy, "sync_weights"):
+                agent_policy.sync_weights()
+
         def run():
             if holder["version"] != self._pool_version():
                 capture()
+            sync_weights()
             run.captures = holder["captures"]
             holder["graph"].replay()
             return (self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner,

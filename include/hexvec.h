@@ -244,6 +244,35 @@ int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const ui
                           const uint8_t *white, int rows, float prob_best, int pool_size, uint64_t seed,
                           uint32_t salt, int advance, unsigned long long *state2, void *stream);
 
+/* The opponents' (or the agent's) actor network evaluated, masked and sampled for a batch of boards in one call:
+ * OpponentPolicy.choose_action -> model.predict(board, deterministic, action_masks=mask) (SelfplayWrapper.py:26-35)
+ * for SB3's default MlpPolicy actor  flatten -> float -> Linear(cells, h1)-Tanh-Linear(h1, h2)-Tanh-Linear(h2, cells)
+ * -> logits -> masked categorical sample (or arg-max if deterministic != 0).  fp32 throughout.
+ *
+ * weights: n_policies networks, network p at weights + p * hexvec_mlp_weights_floats(cells, h1, h2) floats, each
+ * packed TRANSPOSED ([input][output], so that one input's weights are contiguous) with cp = cells rounded up to 16:
+ *     W1t [cells][h1] | b1 [h1] | W2t [h1][h2] | b2 [h2] | W3t [h2][cp] (columns >= cells zero) | b3 [cp]
+ * h1, h2 multiples of 16 in [16, 256]; the base pointer 64-byte aligned (every row then is).
+ * Which network plays a board: slot == NULL -> network 0 for every board.  Otherwise board r uses
+ *     policy_of_slot[clamp(slot[r] + slot_bias, 0, n_slots - 1)]     (policy_of_slot == NULL: that index itself),
+ * i.e. with slot_bias = 1 the vectorised SelfPlayEnv's slot array (-1 = best model, k = pool member k,
+ * SelfplayWrapper.py:97-104) indexes a table whose entry 0 is the best model; several slots may name one network
+ * (the reference's pool mostly holds the same live model).  With more than one network the boards are grouped by
+ * network on the device first (counting sort; `scratch` = hexvec_mlp_scratch_bytes(rows, n_policies) bytes of device
+ * memory, contents irrelevant); each workgroup then serves 64 boards of one network.
+ * obs int8 [rows, cells] (the mover's view, as the step calls emit it), legal uint8 [rows, cells], row_active uint8
+ * [rows] or NULL (boards with 0 get action 0 and are skipped), actions int32 [rows], logits_out float32 [rows, cells] or
+ * NULL (the raw logits of the boards that were evaluated; other rows untouched).  Random numbers, state2, salt, advance
+ * and bad_rows exactly as in hexvec_sample_masked: the call returns the actions hexvec_sample_masked would return on
+ * logits_out.  All pointers are device pointers. */
+size_t hexvec_mlp_weights_floats(int cells, int h1, int h2);
+size_t hexvec_mlp_scratch_bytes(int rows, int n_policies);
+int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const uint8_t *row_active, const int64_t *slot,
+                       int slot_bias, const int32_t *policy_of_slot, int n_slots, int rows, int cells,
+                       const float *weights, int n_policies, int h1, int h2, int deterministic, uint64_t seed,
+                       uint32_t salt, int advance, unsigned long long *state2, int32_t *actions, float *logits_out,
+                       unsigned long long *bad_rows, void *scratch, size_t scratch_bytes, void *stream);
+
 int hexvec_board_size(const hexvec_t *h);
 int hexvec_num_envs(const hexvec_t *h);
 uint32_t hexvec_flags(const hexvec_t *h);

@@ -685,3 +685,148 @@ def test_pick_opponents_kernel_selects_the_right_boards(hx):
                                           C.c_uint64(11), 2, 1, p(state), None))
     torch.cuda.synchronize()
     assert int(state[0]) == before + 1 and float((slot_a[sel1] != slot_b[sel1]).double().mean()) > 0.3
+
+
+def _random_position(rows, cells, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    obs = (torch.randint(0, 3, (rows, cells), generator=g, device="cuda") - 1).to(torch.int8)
+    legal = (obs == 0).to(torch.uint8)
+    return obs, legal
+
+
+@pytest.mark.parametrize("n,hidden,rows", [(5, (64, 64), 1000), (7, (64, 64), 4096), (11, (64, 64), 777),
+                                           (13, (32, 48), 300), (19, (128, 64), 130), (4, (16, 16), 65)])
+def test_fused_actor_matches_fp32_torch_forward(hx, n, hidden, rows):
+    """hexvec_mlp_actions (forward + mask + sample in one launch) against the plain torch fp32 forward of the
+    same network: logits within 2e-5 absolute (fp32 FMA order + the kernel's exp-based tanh, |err| < 2e-7 per
+    activation), the sampled actions exactly those hexvec_sample_masked draws from the kernel's own logits,
+    arg-max actions exactly torch's on those logits; skipped and degenerate boards as in the sampler"""
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy, mlp_actions, sample_masked
+    torch.manual_seed(n)
+    C_ = n * n
+    pol = MlpActorPolicy(C_, hidden).cuda()
+    with torch.no_grad():                               # livelier than the default init: tanh well off its linear range
+        for p_ in pol.parameters():
+            p_.mul_(3.0)
+    obs, legal = _random_position(rows, C_, 5)
+    legal[3] = 0                                        # a board without a legal cell
+    active = torch.ones(rows, dtype=torch.uint8, device="cuda")
+    active[7::5] = 0
+    logits = torch.full((rows, C_), float("nan"), device="cuda")
+    bad = torch.zeros((), dtype=torch.long, device="cuda")
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    a = mlp_actions(pol.packed(), C_, hidden[0], hidden[1], obs, legal, row_active=active, logits_out=logits,
+                    bad_rows=bad, rng=(st, 1234, 9, False))
+    with torch.no_grad():
+        ref = pol.action_net(pol.policy_net(obs.float()))
+    on = active.bool()
+    assert bool(torch.isnan(logits[~on]).all())         # skipped boards: not evaluated, action 0
+    assert bool((a[~on] == 0).all())
+    err = float((logits[on] - ref[on]).abs().max())
+    assert err < 2e-5, err
+    bad2 = torch.zeros((), dtype=torch.long, device="cuda")
+    b = sample_masked(logits.nan_to_num(0.0), legal, None, bad2, row_active=active, rng=(st, 1234, 9, False))
+    assert torch.equal(a, b) and int(bad) == int(bad2) == (1 if bool(on[3]) else 0)
+    assert bool(legal[on].gather(1, a[on].long().view(-1, 1)).view(-1)[legal[on].sum(1) > 0].all())
+    # arg-max play
+    det = mlp_actions(pol.packed(), C_, hidden[0], hidden[1], obs, legal, deterministic=True, logits_out=logits)
+    want = logits.masked_fill(legal == 0, float("-inf")).argmax(1)
+    ok = legal.sum(1) > 0
+    assert torch.equal(det[ok].long(), want[ok])
+    # the policy object takes the same path, and follows in-place weight updates
+    pol.deterministic = True
+    assert pol.fusable and torch.equal(pol.choose_actions(obs.view(rows, n, n), legal), det)
+    with torch.no_grad():
+        pol.action_net.bias.add_(torch.randn(C_, device="cuda") * 5)
+    det2 = pol.choose_actions(obs, legal)
+    with torch.no_grad():
+        want2 = pol.action_net(pol.policy_net(obs.float())).masked_fill(legal == 0, float("-inf")).argmax(1)
+    assert float((det2[ok].long() == want2[ok]).double().mean()) > 0.999 and not torch.equal(det2, det)
+
+
+def test_fused_actor_serves_a_pool_of_networks_in_one_call(hx):
+    """every board names its own network through its opponent slot (SelfplayWrapper.py:97-104): the boards are
+    grouped on the device and each gets the logits of ITS network; the result is independent of the grouping"""
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy, mlp_actions, sample_masked
+    torch.manual_seed(3)
+    n, rows, P = 7, 5000, 6
+    C_ = n * n
+    pols = [MlpActorPolicy(C_).cuda() for _ in range(P)]
+    table = torch.stack([p_.packed() for p_ in pols])
+    obs, legal = _random_position(rows, C_, 11)
+    of_slot = torch.tensor([0, 3, 1, 1, 5, 2, 4, 0, 3], dtype=torch.int32, device="cuda")   # 9 slots -> 6 networks
+    slot = torch.randint(-1, 8, (rows,), device="cuda")
+    slot[:4000] = -1                                     # 80 % on the best model, like the reference
+    slot = slot[torch.randperm(rows, device="cuda")].contiguous()
+    active = (torch.rand(rows, device="cuda") < 0.7).to(torch.uint8)
+    logits = torch.full((rows, C_), float("nan"), device="cuda")
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+    a = mlp_actions(table, C_, 64, 64, obs, legal, row_active=active, slot=slot, slot_bias=1, policy_of_slot=of_slot,
+                    logits_out=logits, rng=(st, 77, 2, True))
+    assert int(st[0]) == 1                               # the call advanced the draw counter
+    st.zero_()
+    which = of_slot[(slot + 1).long()].long()
+    with torch.no_grad():
+        ref = torch.stack([p_.action_net(p_.policy_net(obs.float())) for p_ in pols])        # [P, rows, C]
+    ref = ref[which, torch.arange(rows, device="cuda")]
+    on = active.bool()
+    assert float((logits[on] - ref[on]).abs().max()) < 2e-5
+    assert bool(torch.isnan(logits[~on]).all()) and bool((a[~on] == 0).all())
+    b = sample_masked(logits.nan_to_num(0.0), legal, None, None, row_active=active, rng=(st, 77, 2, False))
+    assert torch.equal(a, b)
+    # one network per call on the boards of that network == the grouped call
+    for u in range(P):
+        sel = (which == u) & on
+        one = mlp_actions(table[u], C_, 64, 64, obs, legal, row_active=sel.to(torch.uint8), rng=(st, 77, 2, False))
+        assert torch.equal(one[sel], a[sel])
+    # clamped slots, no active board at all, a tiny batch
+    wild = slot.clone()
+    wild[:10] = 1000
+    mlp_actions(table, C_, 64, 64, obs, legal, slot=wild, slot_bias=1, policy_of_slot=of_slot, rng=(st, 1, 0, False))
+    none = mlp_actions(table, C_, 64, 64, obs, legal, row_active=torch.zeros_like(active), slot=slot, slot_bias=1,
+                       policy_of_slot=of_slot, rng=(st, 1, 0, False))
+    assert bool((none == 0).all())
+    few = mlp_actions(table, C_, 64, 64, obs[:3], legal[:3], slot=slot[:3].contiguous(), slot_bias=1, policy_of_slot=of_slot,
+                      rng=(st, 77, 2, False))
+    assert few.shape == (3,)
+    with pytest.raises(ValueError):                     # a table that is not in the packed layout of this shape
+        mlp_actions(table[:, :-16].contiguous(), C_, 64, 64, obs, legal)
+
+
+def test_vec_selfplay_pool_of_distinct_networks_is_one_launch_per_round(hx):
+    """VecSelfPlayEnv with a pool of DISTINCT actor networks: the weights-table path (one policy launch per
+    opponent round) plays exactly what the per-policy grouped path plays (arg-max opponents: no random draws
+    to line up), and keeps following pool updates"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    n, E = 5, 2048
+    torch.manual_seed(1)
+    nets = [MlpActorPolicy(n * n, deterministic=True).cuda() for _ in range(4)]
+
+    def make(fused):
+        env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=6, base_model=nets[0], seed=4)
+        for k in range(6):
+            env.set_opponent_model(k, nets[k % 4], float(k))
+        if not fused:
+            env._pool_table = lambda: None
+        return env
+
+    ea, eb = make(True), make(False)
+    assert ea._pool_table() is not None and len(ea._pool_table().policies) == 4
+    oa, la = ea.reset()
+    ob, lb = eb.reset()
+    assert torch.equal(oa, ob) and torch.equal(la, lb)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ended = 0
+    for t in range(40):
+        if t == 20:                                      # a pool update in the middle (SelfPlayCallback's cycle)
+            fresh = MlpActorPolicy(n * n, deterministic=True).cuda()
+            ea.set_opponent_model(2, fresh, 9.0)
+            eb.set_opponent_model(2, fresh, 9.0)
+        act = torch.multinomial(la.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        ra, rb = ea.step(act), eb.step(act)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), t
+        la = ra[3]
+        ended += int(ra[2].sum())
+    assert ended > E and ea.degenerate_rows() == 0
+    assert torch.equal(ea.slot, eb.slot)
