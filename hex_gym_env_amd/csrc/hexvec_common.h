@@ -56,6 +56,15 @@ __device__ __forceinline__ u32 mix32(u32 x)
     x ^= x >> 16;
     return x;
 }
+// Gumbel(0, 1) noise from 32 hash bits: G = -ln(-ln(u)), u = (top 24 bits + 0.5) / 2^24 in (0, 1).  Raw v_log_f32
+// (log2) twice: neither argument can be subnormal (u >= 2^-25, -log2(u) >= 8.6e-8), so the library log's range
+// fix-ups are not needed.  Every sampling kernel uses THIS function: equal hashes give bit-equal noise.
+__device__ __forceinline__ float gumbel_from_hash(u32 h)
+{
+    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float e = -__builtin_amdgcn_logf(u);                            // -log2(u)
+    return __builtin_fmaf(-0.69314718f, __builtin_amdgcn_logf(e), 0.36651292f); // -ln(ln2 * e)
+}
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u32 rflu(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u32 rdlane(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }

@@ -3,15 +3,25 @@
 // model.predict(board, deterministic, action_masks=mask) (SelfplayWrapper.py:26-35) with SB3's default
 // MlpPolicy actor: flatten -> float -> Linear-Tanh-Linear-Tanh -> Linear -> logits -> masked categorical.
 // Every board may name its own network (its opponent slot, SelfplayWrapper.py:97-104): the boards are first
-// grouped by network with a counting sort (three small kernels) so that each workgroup serves 64 boards
-// of one network; the torch spelling evaluates every distinct pool member on the whole batch.
+// grouped by network with a counting sort (three small kernels) so that a tile of boards shares one
+// network; the torch spelling evaluates every distinct pool member on the whole batch.
 //
-// Layout of the work: a workgroup = 64 boards x 4 wavefronts; lane = board; the wavefronts split the
-// OUTPUT neurons of each layer in chunks of 16.  Weights are wave-uniform, so they come through the
-// scalar cache (s_load_dwordx16 of a transposed, 64-byte-aligned row) and every lane runs fp32 FMAs
-// against its own activation, which the layers hand over through LDS as [neuron][lane] (conflict-free).
-// fp32 throughout (the logits must match the fp32 reference closely enough to give the same samples;
-// fp32 MFMA has the same peak as packed fp32 VALU on this chip, so the matrix cores buy nothing here).
+// fp32 throughout: the logits must match the fp32 reference closely enough to give the same samples.
+//
+// k_mlp64_mfma (hidden widths 64-64, SB3's default = what the reference's scripts train): one wavefront =
+// 32 boards, the three layers as chains of v_mfma_f32_32x32x2_f32 with the NEURONS on the M side and the
+// BOARDS on the N side: D[neuron][board] leaves every lane holding its own board's column, 16 neurons in
+// 16 registers -- which is exactly the B operand (k = neuron, n = board) of the next layer's MFMAs if that
+// layer's weights are stored in the matching k order.  So the activations never leave the registers: no
+// LDS, no transposes between the layers; tanh and the Gumbel-max epilogue run on the accumulators in place.
+// The bias rides as one more k step against a constant-one input.  Weights stream from L2 as one coalesced
+// 256-byte read per MFMA (hexvec_mlp_pack stores them in that order).
+//
+// k_mlp_actions (any widths that are multiples of 16): a workgroup = 64 boards x 4 wavefronts; lane =
+// board; the wavefronts split the OUTPUT neurons of each layer in chunks of 16; weights are wave-uniform
+// and come through the scalar cache (s_load_dwordx16 of a transposed row) into v_pk_fma_f32; activations
+// pass between the layers through LDS as [neuron][lane].
+//
 // Sampling is the Gumbel-max of hexvec_sample.hip with the same counter hash: the fused call returns the
 // actions hexvec_sample_masked returns on this kernel's logits.
 #include "hexvec_common.h"
@@ -44,6 +54,33 @@ __host__ __device__ inline MlpShape mlp_shape(int cells, int h1, int h2)
     return s;
 }
 
+// the MFMA layout (h1 == h2 == 64): per MFMA one 64-float record, lane l's element = the A operand of lane l.
+//   layer 1: T1 = ceil((cells + 1) / 2) steps x 2 neuron tiles; step t pairs the inputs (t, T1 + t) -- input
+//            `cells` is the constant one (its weights = the bias), inputs beyond it have zero weights;
+//   layer 2: 33 steps x 2 tiles; step s < 32 pairs the neurons that one accumulator register of layer 1 holds in
+//            the two half-waves (mfma_in()); step 32 is the bias against {1, 0};
+//   layer 3: MT3 = ceil(cells / 32) rounded up to even output tiles x 33 steps.
+struct MfmaShape {
+    int cells, T1, MT3;
+    long long o_w2, o_w3, stride;
+};
+__host__ __device__ inline MfmaShape mfma_shape(int cells)
+{
+    MfmaShape s;
+    s.cells = cells;
+    s.T1 = (cells + 2) / 2;
+    s.MT3 = ((cells + 31) / 32 + 1) & ~1;
+    s.o_w2 = 64LL * 2 * s.T1;
+    s.o_w3 = s.o_w2 + 64LL * 2 * 33;
+    s.stride = s.o_w3 + 64LL * 33 * s.MT3;
+    return s;
+}
+__host__ __device__ inline bool mlp_on_mfma(int h1, int h2) { return h1 == 64 && h2 == 64; }
+// neuron (row of the 32x32 tile) that accumulator register v holds in half-wave `half`
+__host__ __device__ inline int mfma_row(int v, int half) { return 8 * (v >> 2) + 4 * half + (v & 3); }
+// input neuron of k step s (< 32) in half-wave `half`: register s % 16 of neuron tile s / 16 of the layer before
+__host__ __device__ inline int mfma_in(int s, int half) { return (s >> 4) * 32 + mfma_row(s & 15, half); }
+
 struct MlpArgs {
     const signed char *obs;
     const unsigned char *legal;
@@ -53,6 +90,7 @@ struct MlpArgs {
     int slot_bias, n_slots, n_policies;
     int rows;
     MlpShape sh;
+    MfmaShape ms;
     const float *weights;
     int deterministic;
     u32 seed_lo, seed_hi, salt;
@@ -174,12 +212,7 @@ __global__ __launch_bounds__(64 * POL_WAVES) void k_mlp_actions(MlpArgs a)
             if (c < cells) {
                 const float z = acc[k];
                 if (a.logits_out && r >= 0) a.logits_out[(size_t)r * cells + c] = z;
-                float v = z;
-                if (!a.deterministic) {
-                    const u32 h = mix32(rkey + (u32)c * 0x9E3779B9U);
-                    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); // in (0, 1)
-                    v = z - __logf(-__logf(u));
-                }
+                const float v = a.deterministic ? z : z + gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
                 const bool on = legal_b[lane * cells + c] != 0;
                 bad = bad || (on && z != z);
                 if (on && v > best) {
@@ -211,6 +244,211 @@ __global__ __launch_bounds__(64 * POL_WAVES) void k_mlp_actions(MlpArgs a)
         const u64 dm = __ballot(degenerate);
         if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
     }
+}
+
+// ---- hidden widths 64-64 on the matrix cores ----
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Pick {
+    float best;
+    int besti;
+    bool bad;
+};
+// one cell of the masked Gumbel-max (the arithmetic of k_sample_masked)
+__device__ __forceinline__ void consider(Pick &p, float z, int c, bool on, int deterministic, u32 rkey)
+{
+    const float v = deterministic ? z : z + gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
+    p.bad = p.bad || (on && z != z);
+    if (on && v > p.best) {
+        p.best = v;
+        p.besti = c;
+    }
+}
+
+constexpr int MF_WAVES = 4; // wavefronts (= tiles of 32 boards) per workgroup; they share nothing
+
+__global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = rfl((int)threadIdx.x >> 6);
+    const int b = lane & 31, half = lane >> 5; // board of the tile; which input of a k pair / which rows of D
+    const int tile = (int)blockIdx.x * MF_WAVES + wave;
+    if (a.ntiles && tile >= 2 * *a.ntiles) return; // (the grouping counts tiles of 64)
+    const int cells = a.ms.cells, T1 = a.ms.T1;
+
+    const int pos = tile * 32 + b;
+    int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
+    if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) { // nobody asked for this board's action
+        if (half == 0) a.actions[r] = 0;
+        r = -1;
+    }
+    const u64 vmask = __ballot(r >= 0);
+    if (vmask == 0) return; // wavefronts are independent: no workgroup barrier anywhere in this kernel
+    const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
+    const int p = rfl(policy_key(a, r0)); // grouped launches: one network per tile
+    const float *__restrict__ wp = a.weights + (size_t)p * (size_t)a.ms.stride;
+
+    // this wavefront's observation and mask rows -> LDS [32][cells] bytes each (a row is contiguous in HBM)
+    const int img = (32 * cells + 15) & ~15;
+    signed char *obs_w = reinterpret_cast<signed char *>(smem) + (size_t)wave * 2 * img;
+    unsigned char *legal_w = reinterpret_cast<unsigned char *>(obs_w) + img;
+    const bool whole = !a.order && tile * 32 + 32 <= a.rows && (((uintptr_t)a.obs | (uintptr_t)a.legal) & 3) == 0;
+    if (whole) { // 32 consecutive boards: one contiguous block of 32 * cells bytes, copied as dwords
+        const u32 *so = reinterpret_cast<const u32 *>(a.obs + (size_t)tile * 32 * cells);
+        const u32 *sl = reinterpret_cast<const u32 *>(a.legal + (size_t)tile * 32 * cells);
+        const int nd = 8 * cells;
+#pragma unroll 4
+        for (int i = lane; i < nd; i += 64) {
+            reinterpret_cast<u32 *>(obs_w)[i] = so[i];
+            reinterpret_cast<u32 *>(legal_w)[i] = sl[i];
+        }
+    } else {
+        for (int b0 = 0; b0 < 32; b0 += 8) { // eight rows' loads in flight together
+            signed char o[8];
+            unsigned char l[8];
+            for (int c0 = 0; c0 < cells; c0 += 64) {
+                const int c = c0 + lane;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int src = __shfl(r, b0 + k);
+                    const bool ok = src >= 0 && c < cells;
+                    o[k] = ok ? a.obs[(size_t)src * cells + c] : (signed char)0;
+                    l[k] = ok ? a.legal[(size_t)src * cells + c] : (unsigned char)0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c < cells) {
+                        obs_w[(b0 + k) * cells + c] = o[k];
+                        legal_w[(b0 + k) * cells + c] = l[k];
+                    }
+            }
+        }
+    }
+    // (LDS writes and the reads below are ordered inside one wavefront by s_waitcnt)
+
+    // layer 1: [64 neurons][32 boards] = W1 [64][cells + 1] x (obs | 1) [cells + 1][32]
+    f32x16 h0 = {0}, h1 = {0};
+    {
+        const float *__restrict__ w = wp + lane;
+#pragma unroll 4
+        for (int t = 0; t < T1; ++t) {
+            const int in = half * T1 + t;
+            const float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
+            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(t * 2 + 0) * 64], x, h0, 0, 0, 0);
+            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(t * 2 + 1) * 64], x, h1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        h0[v] = tanh_fast(h0[v]);
+        h1[v] = tanh_fast(h1[v]);
+    }
+    // layer 2: the accumulators of layer 1 ARE the B operands (k = neuron, n = board)
+    const float one = half == 0 ? 1.0f : 0.0f; // the bias step's input pair {1, 0}
+    f32x16 g0 = {0}, g1 = {0};
+    {
+        const float *__restrict__ w = wp + a.ms.o_w2 + lane;
+#pragma unroll
+        for (int s = 0; s < 33; ++s) {
+            const float x = s < 16 ? h0[s & 15] : s < 32 ? h1[s & 15] : one;
+            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(s * 2 + 0) * 64], x, g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(s * 2 + 1) * 64], x, g1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        g0[v] = tanh_fast(g0[v]);
+        g1[v] = tanh_fast(g1[v]);
+    }
+    // layer 3, two tiles of 32 cells at a time; masked Gumbel-max (or arg-max) on the accumulators
+    const unsigned long long ctr = a.state ? a.state[0] : 0ULL;
+    const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
+    const u32 rkey = mix32(((u32)r + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi ^ (c_hi * 0xC2B2AE35U) ^
+                     mix32(a.salt * 0x27D4EB2FU + 0x165667B1U); // = k_sample_masked's row key
+    Pick pk = {-INFINITY, 0x7fffffff, false};
+    for (int mt = 0; mt < a.ms.MT3; mt += 2) {
+        f32x16 z0 = {0}, z1 = {0};
+        const float *__restrict__ w = wp + a.ms.o_w3 + (size_t)mt * 33 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 33; ++s) {
+            const float x = s < 16 ? g0[s & 15] : s < 32 ? g1[s & 15] : one;
+            z0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s * 64], x, z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(33 + s) * 64], x, z1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int c = (mt + j) * 32 + mfma_row(v, half);
+                if (c < cells) {
+                    const float z = j == 0 ? z0[v] : z1[v];
+                    if (a.logits_out && r >= 0) a.logits_out[(size_t)r * cells + c] = z;
+                    consider(pk, z, c, legal_w[b * cells + c] != 0, a.deterministic, rkey);
+                }
+            }
+    }
+    // the two half-waves hold complementary cells of the same board
+    {
+        const float ob = __shfl_xor(pk.best, 32);
+        const int oi = __shfl_xor(pk.besti, 32);
+        const int obad = __shfl_xor(pk.bad ? 1 : 0, 32);
+        const bool take = ob > pk.best || (ob == pk.best && oi < pk.besti); // ties go to the lower cell
+        pk.best = take ? ob : pk.best;
+        pk.besti = take ? oi : pk.besti;
+        pk.bad = pk.bad || obad != 0;
+    }
+    const bool mine = half == 0 && r >= 0;
+    const bool degenerate = mine && (pk.bad || !(pk.best > -INFINITY));
+    if (mine) a.actions[r] = degenerate ? 0 : pk.besti;
+    const u64 dm = __ballot(degenerate);
+    if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
+}
+
+// row-major Linear weights ([out][in], torch's layout) -> the packed form of one network
+__global__ __launch_bounds__(256) void k_mlp_pack(const float *w1, const float *b1, const float *w2, const float *b2,
+                                                  const float *w3, const float *b3, int cells, int h1, int h2, float *dst)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    float val = 0.0f;
+    if (mlp_on_mfma(h1, h2)) {
+        const MfmaShape m = mfma_shape(cells);
+        if (idx >= m.stride) return;
+        const int l = (int)(idx & 63), out32 = l & 31, hf = l >> 5;
+        if (idx < m.o_w2) {
+            const int t = (int)(idx >> 7), out = (int)((idx >> 6) & 1) * 32 + out32, in = hf * m.T1 + t;
+            val = in < cells ? w1[(size_t)out * cells + in] : (in == cells ? b1[out] : 0.0f);
+        } else if (idx < m.o_w3) {
+            const long long j = idx - m.o_w2;
+            const int s = (int)(j >> 7), out = (int)((j >> 6) & 1) * 32 + out32;
+            val = s < 32 ? w2[(size_t)out * 64 + mfma_in(s, hf)] : (hf == 0 ? b2[out] : 0.0f);
+        } else {
+            const long long j = idx - m.o_w3;
+            const int mt = (int)(j / (33 * 64)), s = (int)((j >> 6) % 33), out = mt * 32 + out32;
+            if (out < cells) val = s < 32 ? w3[(size_t)out * 64 + mfma_in(s, hf)] : (hf == 0 ? b3[out] : 0.0f);
+        }
+    } else { // W1t [cells][h1] | b1 | W2t [h1][h2] | b2 | W3t [h2][cp] | b3 [cp]
+        const MlpShape m = mlp_shape(cells, h1, h2);
+        if (idx >= m.stride) return;
+        if (idx < m.o_b1) {
+            val = w1[(size_t)(idx % h1) * cells + idx / h1];
+        } else if (idx < m.o_w2) {
+            val = b1[idx - m.o_b1];
+        } else if (idx < m.o_b2) {
+            const long long j = idx - m.o_w2;
+            val = w2[(size_t)(j % h2) * h1 + j / h2];
+        } else if (idx < m.o_w3) {
+            val = b2[idx - m.o_b2];
+        } else if (idx < m.o_b3) {
+            const long long j = idx - m.o_w3;
+            const int out = (int)(j % m.cp);
+            val = out < cells ? w3[(size_t)out * h2 + j / m.cp] : 0.0f;
+        } else {
+            const int out = (int)(idx - m.o_b3);
+            val = out < cells ? b3[out] : 0.0f;
+        }
+    }
+    dst[idx] = val;
 }
 
 // advances the draw counter behind the sampling workgroups (see k_sample_bump, hexvec_sample.hip)
@@ -282,10 +520,34 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_scatter(MlpArgs a, const in
 
 } // namespace hv
 
+static bool mlp_shape_ok(int cells, int h1, int h2)
+{
+    return cells >= 1 && cells <= HEXVEC_MAX_BOARD * HEXVEC_MAX_BOARD && h1 >= 16 && h2 >= 16 && !(h1 & 15) && !(h2 & 15) &&
+           h1 <= 256 && h2 <= 256;
+}
+
 extern "C" size_t hexvec_mlp_weights_floats(int cells, int h1, int h2)
 {
-    if (cells < 1 || h1 < 16 || h2 < 16 || (h1 & 15) || (h2 & 15)) return 0;
-    return (size_t)hv::mlp_shape(cells, h1, h2).stride;
+    if (!mlp_shape_ok(cells, h1, h2)) return 0;
+    return (size_t)(hv::mlp_on_mfma(h1, h2) ? hv::mfma_shape(cells).stride : hv::mlp_shape(cells, h1, h2).stride);
+}
+
+extern "C" int hexvec_mlp_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                               const float *b3, int cells, int h1, int h2, float *dst, void *stream)
+{
+    if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !dst || !mlp_shape_ok(cells, h1, h2)) {
+        hv::set_error("hexvec_mlp_pack", "NULL argument, cells out of range or hidden widths not multiples of 16 in [16, 256]");
+        return HEXVEC_E_ARG;
+    }
+    const size_t n = hexvec_mlp_weights_floats(cells, h1, h2);
+    hipLaunchKernelGGL(hv::k_mlp_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2,
+                       w3, b3, cells, h1, h2, dst);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        hv::set_error("hexvec_mlp_pack", hipGetErrorString(e));
+        return HEXVEC_E_HIP;
+    }
+    return HEXVEC_OK;
 }
 
 extern "C" size_t hexvec_mlp_scratch_bytes(int rows, int n_policies)
@@ -307,9 +569,7 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
         return HEXVEC_E_ARG;
     };
     if (!obs || !legal || !weights || !actions || rows < 0) return fail("obs / legal / weights / actions NULL or rows < 0");
-    if (cells < 1 || cells > HEXVEC_MAX_BOARD * HEXVEC_MAX_BOARD) return fail("cells out of range");
-    if (h1 < 16 || h2 < 16 || (h1 & 15) || (h2 & 15) || h1 > 256 || h2 > 256)
-        return fail("hidden widths must be multiples of 16 in [16, 256]");
+    if (!mlp_shape_ok(cells, h1, h2)) return fail("cells out of range or hidden widths not multiples of 16 in [16, 256]");
     if (n_policies < 1 || n_policies > MAX_POLICIES) return fail("n_policies out of range");
     if (!deterministic && !state2) return fail("sampling needs the draw counter (state2)");
     if (((uintptr_t)weights & 63) != 0) return fail("weights must be 64-byte aligned");
@@ -331,6 +591,7 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
     a.n_policies = n_policies;
     a.rows = rows;
     a.sh = mlp_shape(cells, h1, h2);
+    a.ms = mfma_shape(cells);
     a.weights = weights;
     a.deterministic = deterministic;
     a.seed_lo = (u32)seed;
@@ -353,18 +614,29 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
         a.row_active = nullptr; // inactive boards are not in the order
         tiles += (unsigned)n_policies;
     }
-    const int img = (64 * cells + 15) & ~15;
-    const size_t lds = 2 * (size_t)img + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * POL_WAVES + 1);
-    static thread_local size_t lds_allowed = 0;
-    if (lds > lds_allowed) {
-        const hipError_t e = hipFuncSetAttribute((const void *)k_mlp_actions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool mfma = mlp_on_mfma(h1, h2);
+    size_t lds;
+    const void *fn;
+    if (mfma) {
+        lds = (size_t)MF_WAVES * 2 * ((32 * (size_t)cells + 15) & ~(size_t)15);
+        fn = (const void *)k_mlp64_mfma;
+    } else {
+        lds = 2 * ((64 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * POL_WAVES + 1);
+        fn = (const void *)k_mlp_actions;
+    }
+    static thread_local size_t lds_allowed[2] = {0, 0};
+    if (lds > lds_allowed[mfma]) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hexvec_mlp_actions", hipGetErrorString(e));
             return HEXVEC_E_HIP;
         }
-        lds_allowed = lds;
+        lds_allowed[mfma] = lds;
     }
-    hipLaunchKernelGGL(k_mlp_actions, dim3(tiles), dim3(64 * POL_WAVES), lds, st, a);
+    if (mfma) // tiles of 32 boards, four to a workgroup
+        hipLaunchKernelGGL(k_mlp64_mfma, dim3((2 * tiles + MF_WAVES - 1) / MF_WAVES), dim3(64 * MF_WAVES), lds, st, a);
+    else
+        hipLaunchKernelGGL(k_mlp_actions, dim3(tiles), dim3(64 * POL_WAVES), lds, st, a);
     if (advance && state2) hipLaunchKernelGGL(k_policy_bump, dim3(1), dim3(1), 0, st, state2);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -66,8 +66,7 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long
         for (int k = 0; k < 4; ++k) {
             const int c = c0 + 16 * k;
             const u32 h = mix32(rkey + (u32)c * 0x9E3779B9U);
-            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f); // in (0, 1)
-            const float v = z[k] - __logf(-__logf(u));
+            const float v = z[k] + gumbel_from_hash(h);
             const bool on = lg[k] != 0;
             bad = bad || (on && z[k] != z[k]);
             if (on && v > best) {

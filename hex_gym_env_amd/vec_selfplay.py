@@ -262,19 +262,20 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
 
     @torch.no_grad()
     def pack_into(self, dst):
-        """write this network into dst (float32 [packed_floats()]) in the library's layout: every matrix
-        transposed to [input][output], the output layer padded to a multiple of 16 columns"""
-        cells, (h1, h2) = self.n_cells, self.hidden
-        cp = (cells + 15) // 16 * 16
+        """write this network into dst (float32 [packed_floats()], device memory) in the library's packed form
+        (hexvec_mlp_pack: one small kernel; the layout is the library's business)"""
+        import ctypes as C
+        from . import _lib
         l1, l2 = [m for m in self.policy_net if isinstance(m, torch.nn.Linear)]
-        dst.zero_()
-        o = 0
-        for w, b, cols in ((l1.weight, l1.bias, h1), (l2.weight, l2.bias, h2), (self.action_net.weight, self.action_net.bias, cp)):
-            k, n = w.shape[1], w.shape[0]
-            dst[o:o + k * cols].view(k, cols)[:, :n].copy_(w.t())
-            o += k * cols
-            dst[o:o + n].copy_(b)
-            o += cols
+        src = [t.detach() for t in (l1.weight, l1.bias, l2.weight, l2.bias, self.action_net.weight, self.action_net.bias)]
+        if not dst.is_cuda or any(t.device != dst.device for t in src):
+            raise RuntimeError("pack_into: the network and dst must live on the same GPU (libhexvec has no CPU path)")
+        src = [t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous() for t in src]
+        if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != self.packed_floats():
+            raise ValueError("dst is not a contiguous float32 tensor of packed_floats() elements")
+        _lib.check(_lib.lib().hexvec_mlp_pack(*[C.c_void_p(t.data_ptr()) for t in src], self.n_cells, self.hidden[0],
+                                              self.hidden[1], C.c_void_p(dst.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream(dst.device).cuda_stream)))
         return dst
 
     def packed(self):

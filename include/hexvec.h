@@ -249,10 +249,12 @@ int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const ui
  * for SB3's default MlpPolicy actor  flatten -> float -> Linear(cells, h1)-Tanh-Linear(h1, h2)-Tanh-Linear(h2, cells)
  * -> logits -> masked categorical sample (or arg-max if deterministic != 0).  fp32 throughout.
  *
- * weights: n_policies networks, network p at weights + p * hexvec_mlp_weights_floats(cells, h1, h2) floats, each
- * packed TRANSPOSED ([input][output], so that one input's weights are contiguous) with cp = cells rounded up to 16:
- *     W1t [cells][h1] | b1 [h1] | W2t [h1][h2] | b2 [h2] | W3t [h2][cp] (columns >= cells zero) | b3 [cp]
- * h1, h2 multiples of 16 in [16, 256]; the base pointer 64-byte aligned (every row then is).
+ * weights: n_policies networks, network p at weights + p * hexvec_mlp_weights_floats(cells, h1, h2) floats, each in the
+ * library's PACKED form written by hexvec_mlp_pack from the six row-major tensors of the three Linear layers
+ * (w [out][in], b [out]: torch's layout; device pointers; one small kernel).  The packed form is opaque -- with
+ * h1 == h2 == 64 (SB3's default, what the reference's scripts train) it is the operand order of the fp32 MFMA
+ * chains, otherwise transposed rows for the scalar-broadcast kernel; h1, h2 multiples of 16 in [16, 256]; the
+ * table's base pointer 64-byte aligned.  Re-pack a network whenever its parameters change.
  * Which network plays a board: slot == NULL -> network 0 for every board.  Otherwise board r uses
  *     policy_of_slot[clamp(slot[r] + slot_bias, 0, n_slots - 1)]     (policy_of_slot == NULL: that index itself),
  * i.e. with slot_bias = 1 the vectorised SelfPlayEnv's slot array (-1 = best model, k = pool member k,
@@ -267,6 +269,8 @@ int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const ui
  * logits_out.  All pointers are device pointers. */
 size_t hexvec_mlp_weights_floats(int cells, int h1, int h2);
 size_t hexvec_mlp_scratch_bytes(int rows, int n_policies);
+int hexvec_mlp_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                    int cells, int h1, int h2, float *dst, void *stream);
 int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const uint8_t *row_active, const int64_t *slot,
                        int slot_bias, const int32_t *policy_of_slot, int n_slots, int rows, int cells,
                        const float *weights, int n_policies, int h1, int h2, int deterministic, uint64_t seed,

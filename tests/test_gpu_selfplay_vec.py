@@ -695,7 +695,9 @@ def _random_position(rows, cells, seed):
 
 
 @pytest.mark.parametrize("n,hidden,rows", [(5, (64, 64), 1000), (7, (64, 64), 4096), (11, (64, 64), 777),
-                                           (13, (32, 48), 300), (19, (128, 64), 130), (4, (16, 16), 65)])
+                                           (14, (64, 64), 500), (19, (64, 64), 200), (4, (64, 64), 33),      # matrix cores
+                                           (13, (32, 48), 300), (19, (128, 64), 130), (4, (16, 16), 65),     # general widths
+                                           (7, (64, 32), 640)])
 def test_fused_actor_matches_fp32_torch_forward(hx, n, hidden, rows):
     """hexvec_mlp_actions (forward + mask + sample in one launch) against the plain torch fp32 forward of the
     same network: logits within 2e-5 absolute (fp32 FMA order + the kernel's exp-based tanh, |err| < 2e-7 per
