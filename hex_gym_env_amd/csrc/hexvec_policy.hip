@@ -265,9 +265,29 @@ __device__ __forceinline__ void consider(Pick &p, float z, int c, bool on, int d
     }
 }
 
+// CNT MFMA operand records (64 floats each; `p` already points at this lane's element)
+template <int CNT> __device__ __forceinline__ void wload(float (&w)[CNT], const float *__restrict__ p)
+{
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) w[i] = p[i * 64];
+}
+
+// Diagnostic build (-DHV_POL_STAMPS, tools/stamp_policy.py): s_memtime at the phase boundaries of every wavefront
+#ifdef HV_POL_STAMPS
+__device__ unsigned long long g_pol_stamps[8192][10];
+#define POL_MARK(i)                                                                        \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (lane == 0 && tile < 8192) g_pol_stamps[tile][i] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define POL_MARK(i) do { } while (0)
+#endif
+
 constexpr int MF_WAVES = 4; // wavefronts (= tiles of 32 boards) per workgroup; they share nothing
 
-__global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
+__global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2))) void k_mlp64_mfma(MlpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)threadIdx.x & 63;
@@ -277,6 +297,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
     if (a.ntiles && tile >= 2 * *a.ntiles) return; // (the grouping counts tiles of 64)
     const int cells = a.ms.cells, T1 = a.ms.T1;
 
+    POL_MARK(0);
     const int pos = tile * 32 + b;
     int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
     if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) { // nobody asked for this board's action
@@ -288,6 +309,15 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
     const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
     const int p = rfl(policy_key(a, r0)); // grouped launches: one network per tile
     const float *__restrict__ wp = a.weights + (size_t)p * (size_t)a.ms.stride;
+
+    // Weights: one coalesced 256-byte record per MFMA, streamed from L2 into registers a whole stage AHEAD of the
+    // MFMAs that use them (layer 2's records and layer 1's first chunk are requested here, before the boards'
+    // rows; the first output tiles' before layer 2 runs, ...): with one wavefront per SIMD nothing else hides the
+    // L2 latency.
+    const float *__restrict__ wl = wp + lane;
+    float w2r[66], wa[32], wb[32];
+    wload(wa, wl);
+    wload(w2r, wl + a.ms.o_w2);
 
     // this wavefront's observation and mask rows -> LDS [32][cells] bytes each (a row is contiguous in HBM)
     const int img = (32 * cells + 15) & ~15;
@@ -325,69 +355,97 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
             }
         }
     }
+    POL_MARK(1); // rows requested and written to LDS
     // (LDS writes and the reads below are ordered inside one wavefront by s_waitcnt)
 
-    // layer 1: [64 neurons][32 boards] = W1 [64][cells + 1] x (obs | 1) [cells + 1][32]
+
+    // layer 1: [64 neurons][32 boards] = W1 [64][cells + 1] x (obs | 1) [cells + 1][32], 16 k steps per chunk
     f32x16 h0 = {0}, h1 = {0};
     {
-        const float *__restrict__ w = wp + lane;
-#pragma unroll 4
-        for (int t = 0; t < T1; ++t) {
-            const int in = half * T1 + t;
-            const float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
-            h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(t * 2 + 0) * 64], x, h0, 0, 0, 0);
-            h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(t * 2 + 1) * 64], x, h1, 0, 0, 0);
+        auto chunk = [&](const float(&w)[32], int t0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { // no branches: the LDS reads of a chunk are issued together; steps past
+                const int t = t0 + i;      // T1 (the last chunk's tail) multiply by zero
+                const int in = half * T1 + t;
+                float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
+                x = t < T1 ? x : 0.0f;
+                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i], x, h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i + 1], x, h1, 0, 0, 0);
+            }
+        };
+        // (a chunk past T1 reads on into the layer-2 / layer-3 records of the same network: in bounds, unused)
+        for (int t0 = 0; t0 < T1; t0 += 32) {
+            wload(wb, wl + (size_t)(t0 + 16) * 128);
+            chunk(wa, t0);
+            wload(wa, wl + (size_t)(t0 + 32) * 128);
+            chunk(wb, t0 + 16);
         }
     }
+    POL_MARK(2); // layer 1
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         h0[v] = tanh_fast(h0[v]);
         h1[v] = tanh_fast(h1[v]);
     }
+    POL_MARK(3); // tanh 1
     // layer 2: the accumulators of layer 1 ARE the B operands (k = neuron, n = board)
+    float w3p[66];
+    const float *__restrict__ w3 = wl + a.ms.o_w3;
+    wload(w3p, w3);
     const float one = half == 0 ? 1.0f : 0.0f; // the bias step's input pair {1, 0}
     f32x16 g0 = {0}, g1 = {0};
-    {
-        const float *__restrict__ w = wp + a.ms.o_w2 + lane;
 #pragma unroll
-        for (int s = 0; s < 33; ++s) {
-            const float x = s < 16 ? h0[s & 15] : s < 32 ? h1[s & 15] : one;
-            g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(s * 2 + 0) * 64], x, g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(s * 2 + 1) * 64], x, g1, 0, 0, 0);
-        }
+    for (int s = 0; s < 33; ++s) {
+        const float x = s < 16 ? h0[s & 15] : s < 32 ? h1[s & 15] : one;
+        g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[2 * s], x, g0, 0, 0, 0);
+        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[2 * s + 1], x, g1, 0, 0, 0);
     }
+    POL_MARK(4); // layer 2
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         g0[v] = tanh_fast(g0[v]);
         g1[v] = tanh_fast(g1[v]);
     }
+    POL_MARK(5); // tanh 2
     // layer 3, two tiles of 32 cells at a time; masked Gumbel-max (or arg-max) on the accumulators
     const unsigned long long ctr = a.state ? a.state[0] : 0ULL;
     const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
     const u32 rkey = mix32(((u32)r + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi ^ (c_hi * 0xC2B2AE35U) ^
                      mix32(a.salt * 0x27D4EB2FU + 0x165667B1U); // = k_sample_masked's row key
     Pick pk = {-INFINITY, 0x7fffffff, false};
-    for (int mt = 0; mt < a.ms.MT3; mt += 2) {
+    // Per pair of output tiles: 66 MFMAs, and -- issued between them, in their shadow -- everything about this
+    // lane's 32 cells that does not depend on the logits: the cell's Gumbel noise, or -inf if it is not a legal cell.
+    const float nscale = a.deterministic ? 0.0f : 1.0f; // arg-max play: no noise
+    for (int mt = 0; mt < a.ms.MT3; mt += 2) { // (MT3 is even; the records of a tile pair are 66 * 64 floats)
         f32x16 z0 = {0}, z1 = {0};
-        const float *__restrict__ w = wp + a.ms.o_w3 + (size_t)mt * 33 * 64 + lane;
+        float nz[32];
 #pragma unroll
         for (int s = 0; s < 33; ++s) {
             const float x = s < 16 ? g0[s & 15] : s < 32 ? g1[s & 15] : one;
-            z0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s * 64], x, z0, 0, 0, 0);
-            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(33 + s) * 64], x, z1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int c = (mt + j) * 32 + mfma_row(v, half);
-                if (c < cells) {
-                    const float z = j == 0 ? z0[v] : z1[v];
-                    if (a.logits_out && r >= 0) a.logits_out[(size_t)r * cells + c] = z;
-                    consider(pk, z, c, legal_w[b * cells + c] != 0, a.deterministic, rkey);
-                }
+            z0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[s], x, z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[33 + s], x, z1, 0, 0, 0);
+            if (s < 32) { // (branch-free: the cell index is clamped for the mask read)
+                const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
+                const bool on = (c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0);
+                const float g = nscale * gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
+                nz[s] = on ? g : -INFINITY;
             }
+        }
+        if (mt + 2 < a.ms.MT3) wload(w3p, w3 + (size_t)(mt + 2) * 33 * 64); // lands while the cells are compared
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
+            const float z = s < 16 ? z0[s & 15] : z1[s & 15];
+            if (a.logits_out && r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = z;
+            const float v = z + nz[s]; // -inf on a cell that is not legal (NaN if z is +inf there: never the maximum)
+            pk.bad = pk.bad || (z != z && nz[s] > -INFINITY);
+            if (v > pk.best) {
+                pk.best = v;
+                pk.besti = c;
+            }
+        }
     }
+    POL_MARK(6); // layer 3 + epilogues
     // the two half-waves hold complementary cells of the same board
     {
         const float ob = __shfl_xor(pk.best, 32);
@@ -403,6 +461,7 @@ __global__ __launch_bounds__(64 * MF_WAVES) void k_mlp64_mfma(MlpArgs a)
     if (mine) a.actions[r] = degenerate ? 0 : pk.besti;
     const u64 dm = __ballot(degenerate);
     if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
+    POL_MARK(7);
 }
 
 // row-major Linear weights ([out][in], torch's layout) -> the packed form of one network
@@ -471,31 +530,44 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_count(MlpArgs a, int *count
     for (int k = (int)threadIdx.x; k < a.n_policies; k += GRP_THREADS) counts[(int)blockIdx.x * a.n_policies + k] = h[k];
 }
 
-__global__ __launch_bounds__(MAX_POLICIES) void k_grp_scan(int n_policies, int *ntiles, int *counts, int *order)
+// one workgroup of 4 wavefronts; lane g of a wavefront = grouping workgroup g (GRP_BLOCKS == 64), wavefront w takes
+// the networks w, w + 4, ...: prefix sums over the workgroups are wavefront scans
+__device__ __forceinline__ int wave_incl_scan(int x, int lane)
 {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        x += lane >= d ? y : 0;
+    }
+    return x;
+}
+__global__ __launch_bounds__(256) void k_grp_scan(int n_policies, int *ntiles, int *counts, int *order)
+{
+    static_assert(GRP_BLOCKS == 64, "one lane per grouping workgroup");
     __shared__ int tot[MAX_POLICIES], start[MAX_POLICIES];
-    const int k = (int)threadIdx.x;
-    int total = 0;
-    if (k < n_policies)
-        for (int g = 0; g < GRP_BLOCKS; ++g) { // exclusive offsets of the workgroups inside bucket k
-            const int c = counts[g * n_policies + k];
-            counts[g * n_policies + k] = total;
-            total += c;
-        }
-    tot[k] = total;
-    __syncthreads();
-    if (k == 0) {
-        int run = 0;
-        for (int j = 0; j < n_policies; ++j) { // buckets start on tile boundaries
-            start[j] = run;
-            run += (tot[j] + 63) & ~63;
-        }
-        *ntiles = run >> 6;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    for (int k = wave; k < n_policies; k += 4) {
+        const int incl = wave_incl_scan(counts[lane * n_policies + k], lane);
+        if (lane == 63) tot[k] = incl;
     }
     __syncthreads();
-    if (k < n_policies) {
-        for (int g = 0; g < GRP_BLOCKS; ++g) counts[g * n_policies + k] += start[k];
-        for (int pos = start[k] + total; pos < start[k] + ((total + 63) & ~63); ++pos) order[pos] = -1;
+    if (wave == 0) { // buckets start on tile boundaries: exclusive scan of the padded sizes, 64 networks per trip
+        int run = 0;
+        for (int k0 = 0; k0 < n_policies; k0 += 64) {
+            const int k = k0 + lane;
+            const int padded = k < n_policies ? (tot[k] + 63) & ~63 : 0;
+            const int incl = wave_incl_scan(padded, lane);
+            if (k < n_policies) start[k] = run + incl - padded;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) *ntiles = run >> 6;
+    }
+    __syncthreads();
+    for (int k = wave; k < n_policies; k += 4) {
+        const int c = counts[lane * n_policies + k];
+        counts[lane * n_policies + k] = start[k] + wave_incl_scan(c, lane) - c; // where workgroup `lane` writes bucket k
+        const int total = tot[k], pad = ((total + 63) & ~63) - total;
+        if (lane < pad) order[start[k] + total + lane] = -1;                    // holes up to the tile boundary
     }
 }
 
@@ -519,6 +591,13 @@ __global__ __launch_bounds__(GRP_THREADS) void k_grp_scatter(MlpArgs a, const in
 }
 
 } // namespace hv
+
+#ifdef HV_POL_STAMPS
+extern "C" int hexvec_debug_policy_stamps(unsigned long long *host_dst, int ntiles)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(hv::g_pol_stamps), (size_t)ntiles * 10 * sizeof(unsigned long long));
+}
+#endif
 
 static bool mlp_shape_ok(int cells, int h1, int h2)
 {
