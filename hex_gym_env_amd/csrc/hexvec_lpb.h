@@ -785,6 +785,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                     }
                     fin = s.done != 0;
                     s.pend = fin ? 0 : 1;
+                    if (!fin && a.done) a.done[o] = 0; // in progress: the caller need not clear the row
                 }
             } else { // the opponent's plies: replies (slot 2) and openings (slot 3)
                 const int was = s.pend;

@@ -532,6 +532,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                     }
                     fin = s.done != 0;
                     s.pend = fin ? 0 : 1;
+                    if (!fin && c.l == 0 && a.done) a.done[o] = 0; // in progress: the caller need not clear the row
                 }
             } else { // the opponent's plies: replies (slot 2) and openings (slot 3)
                 const int was = s.pend;

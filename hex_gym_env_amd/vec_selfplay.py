@@ -289,7 +289,26 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
             self._packed_version = v
         return self._packed
 
-    sync_weights = packed        # call before replaying a captured graph that contains choose_actions
+    @torch.no_grad()
+    def opening_logits(self):
+        """logits of the EMPTY board, float32 [1, n_cells] (every cell legal): the opening distribution of this
+        network.  Cached in a static buffer and recomputed only when the parameters changed -- a self-play step
+        samples openings from it without running the network."""
+        v = self.weights_version()
+        dev = self.action_net.weight.device
+        if getattr(self, "_open_logits", None) is None or self._open_logits.device != dev:
+            self._open_logits = torch.empty((1, self.n_cells), dtype=torch.float32, device=dev)
+            self._open_version = None
+        if self._open_version != v:
+            self._open_logits.copy_(self.action_net(self.policy_net(torch.zeros((1, self.n_cells), device=dev))))
+            self._open_version = v
+        return self._open_logits
+
+    def sync_weights(self):
+        """refresh everything derived from the parameters (call before replaying a captured graph that
+        contains choose_actions / openings of this policy)"""
+        self.opening_logits()
+        return self.packed() if self.fusable else None
 
     @torch.no_grad()
     def choose_actions(self, obs, legal, row_active=None, out=None, rng=None):
@@ -522,7 +541,8 @@ class VecSelfPlayEnv:
         full = self._all_legal
         for pol, slots in groups.values():
             if hasattr(pol, "logits"):
-                z = pol.logits(self._empty_board[:1], full[:1])     # one row, shared by every board
+                # one row, shared by every board (cached per parameter version where the policy offers that)
+                z = pol.opening_logits() if hasattr(pol, "opening_logits") else pol.logits(self._empty_board[:1], full[:1])
                 if getattr(pol, "deterministic", False):
                     a = z.argmax(1).to(torch.int32).expand(E)
                 else:
@@ -588,7 +608,6 @@ class VecSelfPlayEnv:
         Finished boards are reset (with a fresh random position if sample_board); their opponent is
         re-drawn before it opens (if it opens).  No host synchronisation: the number of opponent
         rounds is fixed (replies, then openings if any agent plays WHITE)."""
-        self.vec.done.zero_()        # the split calls write only the boards whose step completes
         if self.buffer.evaluating or self.sample_board:
             return self._step_general(actions)
         # the common case: every slot update is one fused launch, the boards that owe no ply are skipped
@@ -673,8 +692,11 @@ class VecSelfPlayEnv:
             tab = self._pool_table()
             if tab is not None:
                 tab.sync()
-            if hasattr(agent_policy, "sync_weights"):
-                agent_policy.sync_weights()
+            seen = set()
+            for pol in [agent_policy] + [self.buffer.policy(k) for k in range(-1, len(self.buffer))]:
+                if id(pol) not in seen and hasattr(pol, "sync_weights"):
+                    seen.add(id(pol))
+                    pol.sync_weights()
 
         def run():
             if holder["version"] != self._pool_version():

@@ -131,7 +131,9 @@ int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *opp_actions,
  *                                         get pending = 2 and show the opponent's view again;
  *   hexvec_step_opponent(opp_actions)     ... repeated until no board is pending.
  * reward / done / winner / terminal_obs are written only for the boards whose step completes
- * in that call, obs / legal / pending (uint8 [E]) for all boards.  actions / opp_actions may be
+ * in that call (hexvec_step_agent also writes done = 0 for the boards it leaves in progress, so
+ * after the agent's call the done row is current for every board), obs / legal / pending
+ * (uint8 [E]) for all boards.  actions / opp_actions may be
  * NULL (uniform-legal RNG).  With opp_actions == NULL throughout, the result (and the RNG stream) equals
  * hexvec_step with the same agent actions; with caller-supplied opp_actions the split step also takes the
  * OPENINGS from the caller (pending == 2 boards) and draws nothing, where hexvec_step draws them itself. */

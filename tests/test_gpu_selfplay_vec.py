@@ -504,6 +504,23 @@ def test_collect_step_as_one_hip_graph(hx):
         tot += int(done.sum())
     assert tot > E and _np(env.episode_stats())[2] - before == tot
     assert env.degenerate_rows(agent) == 0 and run.captures == 1
+    # the packed weights and the cached opening logits are static buffers of the graph; run() refreshes them when
+    # the live networks change in place (training between collection phases): same graph, new behaviour
+    with torch.no_grad():
+        agent.action_net.bias[5] += 1000.0              # the agent now plays cell 5 whenever it is empty
+        for net in (opp, opp2):
+            net.action_net.bias[n * n - 1] += 1000.0    # ... and every opponent opens in the last cell
+    seen_open = 0
+    for k in range(12):
+        prev_legal = env.vec.legal.clone()
+        obs, rew, done, legal, win, act = run()
+        can = prev_legal[:, 5] != 0
+        assert bool((act[can] == 5).all()), k
+        o = obs.reshape(E, -1)
+        opened = (col != 0) & ((o != 0).sum(1) == 1)    # a fresh board on which only the opponent has played
+        assert bool((o[opened][:, n * n - 1] == 1).all())
+        seen_open += int(opened.sum())
+    assert run.captures == 1 and seen_open > 0
 
 
 def test_captured_collect_step_follows_the_opponent_pool(hx):
