@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="length of the CPU-baseline sample")
     ap.add_argument("--no-host-stepped", action="store_true")
     ap.add_argument("--no-w2", action="store_true", help="skip the two-sided rollout leg")
+    ap.add_argument("--no-collect", action="store_true",
+                    help="skip the policy-in-the-loop leg (BASELINE config 3: 7x7, 32 768 envs, SelfplayWrapper + MLP policy)")
     ap.add_argument("--layout", choices=["auto", "rollout", "bitboard"], default="auto",
                     help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT); "
                          "auto = by the number of wavefronts the geometry gives (HexVecEnv rollout_layout='auto')")
@@ -248,6 +250,37 @@ def main():
                                "achieved_GBps": plies * (2 * C + 9) / 1e9,
                                "frac": plies * (2 * C + 9) / 1e9 / HBM_PEAK_GBPS,
                                "kernel": env2.last_kernel()}
+
+    # BASELINE config 3, policy in the loop (secondary, N = 1 only): one PPO-style collection step = the agent's
+    # actor network + masked sampling + SelfPlayEnv.step with MLP opponents from a 20-slot pool, every board its
+    # own opponent slot, captured as one hipGraph.  fp32 networks with random-init weights of SB3's default shape.
+    if not args.no_collect and world == 1:
+        try:
+            from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+            n3, E3 = 7, 32768
+            torch.manual_seed(0)
+            agent, opp = MlpActorPolicy(n3 * n3).to(dev), MlpActorPolicy(n3 * n3).to(dev)
+            env3 = VecSelfPlayEnv(board_size=n3, num_envs=E3, buffer_size=20, base_model=opp, seed=1, device=dev)
+            env3.reset()
+            run = env3.capture_collect_step(agent)
+            for _ in range(200):
+                run()
+            fence()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            kc = 500
+            g0.record()
+            for _ in range(kc):
+                run()
+            g1.record()
+            fence()
+            us = 1e3 * g0.elapsed_time(g1) / kc
+            extra["collect_step"] = {"workload": "7x7, 32768 envs, SelfplayWrapper semantics, MLP 64-64 agent and opponents "
+                                                 "(20-slot pool), one hipGraph per collection step",
+                                     "us_per_step": us, "agent_steps_per_s": E3 / (us * 1e-6),
+                                     "degenerate_rows": env3.degenerate_rows(agent)}
+            del env3, run
+        except Exception as e:  # the secondary leg never takes the headline down with it
+            extra["collect_step"] = {"error": repr(e)}
 
     # episode statistics: the only cross-GPU exchange (logging), one all-gather over RCCL
     per_rank, stats = hxdist.gather_episode_stats(env.episode_stats())
