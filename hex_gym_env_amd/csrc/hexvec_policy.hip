@@ -464,6 +464,195 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
     POL_MARK(7);
 }
 
+// The same network with TWO wavefronts per tile of 32 boards, for launches that would otherwise leave one lone
+// wavefront per SIMD (or fewer): wavefront w owns neuron tile w of both hidden layers and the output tiles
+// w, w + 2, ...; the activations cross between the two through LDS ([neuron][board] floats, one workgroup barrier
+// per layer).  Per wavefront half the MFMAs, half the tanh and half the sampling epilogue; the weight records are
+// the same (each wavefront reads those of its own tiles).  Bit-identical logits to k_mlp64_mfma (same chains).
+__global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)threadIdx.x & 63;
+    const int w = rfl((int)threadIdx.x >> 6);
+    const int b = lane & 31, half = lane >> 5;
+    const int tile = (int)blockIdx.x;
+    if (a.ntiles && tile >= 2 * *a.ntiles) return; // (workgroup-uniform, like every exit below)
+    const int cells = a.ms.cells, T1 = a.ms.T1;
+
+    const int pos = tile * 32 + b;
+    int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
+    if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) {
+        if (half == 0 && w == 0) a.actions[r] = 0;
+        r = -1;
+    }
+    const u64 vmask = __ballot(r >= 0);
+    if (vmask == 0) return;
+    const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
+    const int p = rfl(policy_key(a, r0));
+    const float *__restrict__ wl = a.weights + (size_t)p * (size_t)a.ms.stride + lane;
+
+    // this wavefront's records: layer 2 (33) and the first 16 steps of layer 1, requested before the boards' rows
+    float w2r[33], wa[16], wb[16];
+    auto wload1 = [&](float(&dst)[16], int t0) { // records (t, tile w), t = t0 .. t0 + 15
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = wl[(size_t)((t0 + i) * 2 + w) * 64];
+    };
+    wload1(wa, 0);
+#pragma unroll
+    for (int s = 0; s < 33; ++s) w2r[s] = wl[a.ms.o_w2 + (size_t)(s * 2 + w) * 64];
+
+    // LDS: obs [32][cells] | legal [32][cells] | hA [64][32] floats | hB [64][32] floats | reduction 3 x [32]
+    const int img = (32 * cells + 15) & ~15;
+    signed char *obs_w = reinterpret_cast<signed char *>(smem);
+    unsigned char *legal_w = smem + img;
+    float *hA = reinterpret_cast<float *>(smem + 2 * img);
+    float *hB = hA + 64 * 32;
+    float *red_v = hB + 64 * 32;
+    int *red_i = reinterpret_cast<int *>(red_v + 32);
+    int *red_b = red_i + 32;
+    const bool whole = !a.order && tile * 32 + 32 <= a.rows && (((uintptr_t)a.obs | (uintptr_t)a.legal) & 3) == 0;
+    if (whole) {
+        const u32 *so = reinterpret_cast<const u32 *>(a.obs + (size_t)tile * 32 * cells);
+        const u32 *sl = reinterpret_cast<const u32 *>(a.legal + (size_t)tile * 32 * cells);
+        const int nd = 8 * cells;
+#pragma unroll 4
+        for (int i = (int)threadIdx.x; i < nd; i += 128) {
+            reinterpret_cast<u32 *>(obs_w)[i] = so[i];
+            reinterpret_cast<u32 *>(legal_w)[i] = sl[i];
+        }
+    } else {
+        for (int b0 = w * 16; b0 < w * 16 + 16; b0 += 8) { // wavefront w fetches boards 16 w .. 16 w + 15
+            signed char o[8];
+            unsigned char l[8];
+            for (int c0 = 0; c0 < cells; c0 += 64) {
+                const int c = c0 + lane;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int src = __shfl(r, b0 + k);
+                    const bool ok = src >= 0 && c < cells;
+                    o[k] = ok ? a.obs[(size_t)src * cells + c] : (signed char)0;
+                    l[k] = ok ? a.legal[(size_t)src * cells + c] : (unsigned char)0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c < cells) {
+                        obs_w[(b0 + k) * cells + c] = o[k];
+                        legal_w[(b0 + k) * cells + c] = l[k];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+
+    // layer 1, neuron tile w
+    f32x16 h = {0};
+    {
+        auto chunk = [&](const float(&wr)[16], int t0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int t = t0 + i;
+                const int in = half * T1 + t;
+                float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
+                x = t < T1 ? x : 0.0f;
+                h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x, h, 0, 0, 0);
+            }
+        };
+        for (int t0 = 0; t0 < T1; t0 += 32) {
+            wload1(wb, t0 + 16);
+            chunk(wa, t0);
+            wload1(wa, t0 + 32);
+            chunk(wb, t0 + 16);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) hA[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(h[v]);
+    // the first of this wavefront's output tiles: requested before layer 2 runs
+    float w3p[33];
+    const float *__restrict__ w3 = wl + a.ms.o_w3;
+#pragma unroll
+    for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)(w * 33 + s) * 64];
+    __syncthreads();
+    // layer 2, neuron tile w: all 64 activations of layer 1 come back from LDS in k-step order
+    const float one = half == 0 ? 1.0f : 0.0f;
+    f32x16 g = {0};
+#pragma unroll
+    for (int s = 0; s < 33; ++s) {
+        const float x = s < 32 ? hA[mfma_in(s, half) * 32 + b] : one;
+        g = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[s], x, g, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) hB[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(g[v]);
+    __syncthreads();
+    float xs[33];
+#pragma unroll
+    for (int s = 0; s < 33; ++s) xs[s] = s < 32 ? hB[mfma_in(s, half) * 32 + b] : one;
+    // layer 3: output tiles w, w + 2, ...
+    const unsigned long long ctr = a.state ? a.state[0] : 0ULL;
+    const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
+    const u32 rkey = mix32(((u32)r + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi ^ (c_hi * 0xC2B2AE35U) ^
+                     mix32(a.salt * 0x27D4EB2FU + 0x165667B1U);
+    Pick pk = {-INFINITY, 0x7fffffff, false};
+    const float nscale = a.deterministic ? 0.0f : 1.0f;
+    for (int mt = w; mt < a.ms.MT3; mt += 2) {
+        f32x16 z = {0};
+        float nz[16];
+#pragma unroll
+        for (int s = 0; s < 33; ++s) {
+            z = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[s], xs[s], z, 0, 0, 0);
+            if (s < 16) { // this lane's 16 cells of the tile: noise (or -inf) in the shadow of the MFMAs
+                const int c = mt * 32 + mfma_row(s, half);
+                const bool on = (c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0);
+                const float gn = nscale * gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
+                nz[s] = on ? gn : -INFINITY;
+            }
+        }
+        if (mt + 2 < a.ms.MT3) {
+#pragma unroll
+            for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)((mt + 2) * 33 + s) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = mt * 32 + mfma_row(s, half);
+            const float zz = z[s];
+            if (a.logits_out && r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = zz;
+            const float v = zz + nz[s];
+            pk.bad = pk.bad || (zz != zz && nz[s] > -INFINITY);
+            if (v > pk.best || (v == pk.best && c < pk.besti)) { // (tiles are visited out of cell order here)
+                pk.best = v;
+                pk.besti = c;
+            }
+        }
+    }
+    {
+        const float ob = __shfl_xor(pk.best, 32);
+        const int oi = __shfl_xor(pk.besti, 32);
+        const int obad = __shfl_xor(pk.bad ? 1 : 0, 32);
+        const bool take = ob > pk.best || (ob == pk.best && oi < pk.besti);
+        pk.best = take ? ob : pk.best;
+        pk.besti = take ? oi : pk.besti;
+        pk.bad = pk.bad || obad != 0;
+    }
+    if (w == 1 && half == 0) {
+        red_v[b] = pk.best;
+        red_i[b] = pk.besti;
+        red_b[b] = pk.bad ? 1 : 0;
+    }
+    __syncthreads();
+    if (w == 0) {
+        const float ob = red_v[b];
+        const int oi = red_i[b];
+        const bool take = ob > pk.best || (ob == pk.best && oi < pk.besti);
+        pk.best = take ? ob : pk.best;
+        pk.besti = take ? oi : pk.besti;
+        pk.bad = pk.bad || red_b[b] != 0;
+        const bool mine = half == 0 && r >= 0;
+        const bool degenerate = mine && (pk.bad || !(pk.best > -INFINITY));
+        if (mine) a.actions[r] = degenerate ? 0 : pk.besti;
+        const u64 dm = __ballot(degenerate);
+        if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
+    }
+}
+
 // row-major Linear weights ([out][in], torch's layout) -> the packed form of one network
 __global__ __launch_bounds__(256) void k_mlp_pack(const float *w1, const float *b1, const float *w2, const float *b2,
                                                   const float *w3, const float *b3, int cells, int h1, int h2, float *dst)
@@ -696,23 +885,36 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
     const bool mfma = mlp_on_mfma(h1, h2);
     size_t lds;
     const void *fn;
-    if (mfma) {
+    // few tiles: two wavefronts per tile, so that every SIMD holds two wavefronts where it would hold one (or none)
+    static const int simds = []() {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 4 * cus;
+    }();
+    const bool split = mfma && (long long)2 * tiles * 2 <= (long long)3 * simds && getenv("HEXVEC_MLP_NOSPLIT") == nullptr;
+    if (mfma && split) {
+        lds = 2 * ((32 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * (2 * 64 * 32 + 3 * 32);
+        fn = (const void *)k_mlp64_mfma2;
+    } else if (mfma) {
         lds = (size_t)MF_WAVES * 2 * ((32 * (size_t)cells + 15) & ~(size_t)15);
         fn = (const void *)k_mlp64_mfma;
     } else {
         lds = 2 * ((64 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * POL_WAVES + 1);
         fn = (const void *)k_mlp_actions;
     }
-    static thread_local size_t lds_allowed[2] = {0, 0};
-    if (lds > lds_allowed[mfma]) {
+    static thread_local size_t lds_allowed[3] = {0, 0, 0};
+    const int which = mfma ? (split ? 2 : 1) : 0;
+    if (lds > lds_allowed[which]) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hexvec_mlp_actions", hipGetErrorString(e));
             return HEXVEC_E_HIP;
         }
-        lds_allowed[mfma] = lds;
+        lds_allowed[which] = lds;
     }
-    if (mfma) // tiles of 32 boards, four to a workgroup
+    if (mfma && split) // one tile of 32 boards per workgroup of two wavefronts
+        hipLaunchKernelGGL(k_mlp64_mfma2, dim3(2 * tiles), dim3(128), lds, st, a);
+    else if (mfma) // tiles of 32 boards, four to a workgroup
         hipLaunchKernelGGL(k_mlp64_mfma, dim3((2 * tiles + MF_WAVES - 1) / MF_WAVES), dim3(64 * MF_WAVES), lds, st, a);
     else
         hipLaunchKernelGGL(k_mlp_actions, dim3(tiles), dim3(64 * POL_WAVES), lds, st, a);
