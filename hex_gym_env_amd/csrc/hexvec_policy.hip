@@ -363,14 +363,19 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
     f32x16 h0 = {0}, h1 = {0};
     {
         auto chunk = [&](const float(&w)[32], int t0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { // no branches: the LDS reads of a chunk are issued together; steps past
-                const int t = t0 + i;      // T1 (the last chunk's tail) multiply by zero
+            float x[16]; // the chunk's 16 inputs first, their LDS reads issued together; steps past T1 (the last
+#pragma unroll           // chunk's tail) multiply by zero
+            for (int i = 0; i < 16; ++i) {
+                const int t = t0 + i;
                 const int in = half * T1 + t;
-                float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
-                x = t < T1 ? x : 0.0f;
-                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i], x, h0, 0, 0, 0);
-                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i + 1], x, h1, 0, 0, 0);
+                const float o = (float)(int)obs_w[b * cells + min(in, cells - 1)];
+                x[i] = t < T1 ? (in < cells ? o : (in == cells ? 1.0f : 0.0f)) : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                h0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i], x[i], h0, 0, 0, 0);
+                h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2 * i + 1], x[i], h1, 0, 0, 0);
             }
         };
         // (a chunk past T1 reads on into the layer-2 / layer-3 records of the same network: in bounds, unused)
@@ -414,35 +419,47 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
                      mix32(a.salt * 0x27D4EB2FU + 0x165667B1U); // = k_sample_masked's row key
     Pick pk = {-INFINITY, 0x7fffffff, false};
     // Per pair of output tiles: 66 MFMAs, and -- issued between them, in their shadow -- everything about this
-    // lane's 32 cells that does not depend on the logits: the cell's Gumbel noise, or -inf if it is not a legal cell.
+    // lane's 32 cells that does not depend on the logits: the cell's Gumbel noise, or -inf if it is not a legal cell
+    // (fp32 MFMAs run on the SIMD's fp32 lanes, so this does not overlap them; it keeps the tail after the last MFMA short).
     const float nscale = a.deterministic ? 0.0f : 1.0f; // arg-max play: no noise
     for (int mt = 0; mt < a.ms.MT3; mt += 2) { // (MT3 is even; the records of a tile pair are 66 * 64 floats)
         f32x16 z0 = {0}, z1 = {0};
         float nz[32];
+        u32 lgm = 0; // bit s: this lane's cell s of the pair is on the board and legal (32 LDS byte reads, issued together)
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
+            lgm |= (u32)((c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0)) << s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 33; ++s) {
             const float x = s < 16 ? g0[s & 15] : s < 32 ? g1[s & 15] : one;
             z0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[s], x, z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[33 + s], x, z1, 0, 0, 0);
-            if (s < 32) { // (branch-free: the cell index is clamped for the mask read)
+            if (s < 32) {
                 const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
-                const bool on = (c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0);
                 const float g = nscale * gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
-                nz[s] = on ? g : -INFINITY;
+                nz[s] = (lgm >> s) & 1u ? g : -INFINITY;
             }
         }
         if (mt + 2 < a.ms.MT3) wload(w3p, w3 + (size_t)(mt + 2) * 33 * 64); // lands while the cells are compared
+        if (a.logits_out) { // (diagnostic / test output: one wave-uniform branch, then predicated stores)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+            for (int s = 0; s < 32; ++s) {
+                const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
+                if (r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = s < 16 ? z0[s & 15] : z1[s & 15];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) { // branch-free: compares and selects only
             const int c = (mt + (s >> 4)) * 32 + mfma_row(s & 15, half);
             const float z = s < 16 ? z0[s & 15] : z1[s & 15];
-            if (a.logits_out && r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = z;
             const float v = z + nz[s]; // -inf on a cell that is not legal (NaN if z is +inf there: never the maximum)
-            pk.bad = pk.bad || (z != z && nz[s] > -INFINITY);
-            if (v > pk.best) {
-                pk.best = v;
-                pk.besti = c;
-            }
+            pk.bad = pk.bad | ((z != z) & (nz[s] > -INFINITY));
+            const bool take = v > pk.best;
+            pk.best = take ? v : pk.best;
+            pk.besti = take ? c : pk.besti;
         }
     }
     POL_MARK(6); // layer 3 + epilogues
@@ -548,14 +565,17 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     f32x16 h = {0};
     {
         auto chunk = [&](const float(&wr)[16], int t0) {
+            float x[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int t = t0 + i;
                 const int in = half * T1 + t;
-                float x = in < cells ? (float)(int)obs_w[b * cells + in] : (in == cells ? 1.0f : 0.0f);
-                x = t < T1 ? x : 0.0f;
-                h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x, h, 0, 0, 0);
+                const float o = (float)(int)obs_w[b * cells + min(in, cells - 1)];
+                x[i] = t < T1 ? (in < cells ? o : (in == cells ? 1.0f : 0.0f)) : 0.0f;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x[i], h, 0, 0, 0);
         };
         for (int t0 = 0; t0 < T1; t0 += 32) {
             wload1(wb, t0 + 16);
@@ -575,10 +595,13 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     // layer 2, neuron tile w: all 64 activations of layer 1 come back from LDS in k-step order
     const float one = half == 0 ? 1.0f : 0.0f;
     f32x16 g = {0};
+    {
+        float x[33];
 #pragma unroll
-    for (int s = 0; s < 33; ++s) {
-        const float x = s < 32 ? hA[mfma_in(s, half) * 32 + b] : one;
-        g = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[s], x, g, 0, 0, 0);
+        for (int s = 0; s < 33; ++s) x[s] = s < 32 ? hA[mfma_in(s, half) * 32 + b] : one;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 33; ++s) g = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[s], x[s], g, 0, 0, 0);
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) hB[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(g[v]);
@@ -586,6 +609,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     float xs[33];
 #pragma unroll
     for (int s = 0; s < 33; ++s) xs[s] = s < 32 ? hB[mfma_in(s, half) * 32 + b] : one;
+    __builtin_amdgcn_sched_barrier(0);
     // layer 3: output tiles w, w + 2, ...
     const unsigned long long ctr = a.state ? a.state[0] : 0ULL;
     const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
@@ -596,31 +620,41 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     for (int mt = w; mt < a.ms.MT3; mt += 2) {
         f32x16 z = {0};
         float nz[16];
+        u32 lgm = 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = mt * 32 + mfma_row(s, half);
+            lgm |= (u32)((c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0)) << s;
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 33; ++s) {
             z = __builtin_amdgcn_mfma_f32_32x32x2f32(w3p[s], xs[s], z, 0, 0, 0);
-            if (s < 16) { // this lane's 16 cells of the tile: noise (or -inf) in the shadow of the MFMAs
+            if (s < 16) { // this lane's 16 cells of the tile: noise (or -inf), between the MFMAs
                 const int c = mt * 32 + mfma_row(s, half);
-                const bool on = (c < cells) & (legal_w[b * cells + min(c, cells - 1)] != 0);
                 const float gn = nscale * gumbel_from_hash(mix32(rkey + (u32)c * 0x9E3779B9U));
-                nz[s] = on ? gn : -INFINITY;
+                nz[s] = (lgm >> s) & 1u ? gn : -INFINITY;
             }
         }
         if (mt + 2 < a.ms.MT3) {
 #pragma unroll
             for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)((mt + 2) * 33 + s) * 64];
         }
+        if (a.logits_out) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int c = mt * 32 + mfma_row(s, half);
+                if (r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = z[s];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int c = mt * 32 + mfma_row(s, half);
-            const float zz = z[s];
-            if (a.logits_out && r >= 0 && c < cells) a.logits_out[(size_t)r * cells + c] = zz;
-            const float v = zz + nz[s];
-            pk.bad = pk.bad || (zz != zz && nz[s] > -INFINITY);
-            if (v > pk.best || (v == pk.best && c < pk.besti)) { // (tiles are visited out of cell order here)
-                pk.best = v;
-                pk.besti = c;
-            }
+            const float v = z[s] + nz[s];
+            pk.bad = pk.bad | ((z[s] != z[s]) & (nz[s] > -INFINITY));
+            const bool take = v > pk.best; // (this wavefront's cells come in increasing order)
+            pk.best = take ? v : pk.best;
+            pk.besti = take ? c : pk.besti;
         }
     }
     {
