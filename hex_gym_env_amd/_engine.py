@@ -51,6 +51,15 @@ class _BoardEngine:
         self._empty = 2 if encoding == "A" else 0
         self._board = self._legal = self._labels = self._cur = None
         self._st = self.env._stream()   # every call below ends in a wait, so one fixed stream is enough
+        # completion ticket: the ply kernel adds 1 to this host-pinned word behind its outputs; ply() spins on it
+        self._t_tk, self._tk, self._p_tk = _pinned((1,), torch.int32)
+        self._tk = self._tk.view(np.uint32)     # the kernel counts modulo 2^32
+        self._tk[0] = 0
+        self._expect = 0
+        _lib.check(self._L.hexvec_set_ticket(self._h, self._p_tk))
+        self._apply = self._L.hexvec_apply_moves
+        self._apply_args = (self._h, self._p_act, 1, self._p_ret, self._p_done, self._p_rb, self._p_lg, self._p_ob,
+                            self._st)
         self._fetch_board()
 
     # -- state transfer -------------------------------------------------
@@ -58,6 +67,7 @@ class _BoardEngine:
         rc = self._L.hexvec_stream_synchronize(self._h, self._st)
         if rc:
             _lib.check(rc)
+        self._expect = int(self._tk[0])    # launches that signalled before this wait are accounted for
 
     def _fetch_board(self):
         """board + labels + player to move of the current position (after a reset / set_position)"""
@@ -80,9 +90,19 @@ class _BoardEngine:
     def ply(self, action):
         """one literal ply; returns (ret code, done flag, reward[0])"""
         self._act[0, 0] = action
-        _lib.check(self._L.hexvec_apply_moves(self._h, self._p_act, 1, self._p_ret, self._p_done, self._p_rb,
-                                              self._p_lg, self._p_ob, self._st))
-        self._wait()
+        rc = self._apply(*self._apply_args)
+        if rc:
+            _lib.check(rc)
+        # wait for the kernel's ticket (one board = +1 per launch) instead of a stream wait
+        want = self._expect = (self._expect + 1) & 0xFFFFFFFF
+        tk = self._tk
+        for _ in range(200000):             # ~10 ms of polling, then the blocking wait decides
+            if tk[0] == want:
+                break
+        else:
+            self._wait()
+            if int(tk[0]) != want:
+                raise RuntimeError("libhexvec: the ply kernel did not signal its completion ticket")
         self._board = self._legal = self._labels = self._cur = None
         return int(self._ret[0, 0]), bool(self._done[0, 0]), int(self._rb[0, 0])
 
@@ -115,3 +135,31 @@ class _BoardEngine:
         if self._cur is None:
             self._fetch_labels()
         return self._cur
+
+
+# Engines are pooled: the reference builds a fresh HexGame at every reset (HexGame.py:228, HexSingleGame.py:209), and
+# a fresh engine here would mean a new device handle plus a dozen pinned allocations per game.  A HexGame look-alike
+# takes an engine with acquire() and hands it back from __del__; set_position() re-initialises it completely.
+# The pool keeps a strong reference to every engine it made (busy or not): an engine must never become part of a
+# garbage cycle together with its HexGame, or the collector would run the device handle's finalizer before
+# HexGame.__del__ could hand the engine back.
+_POOL = {}
+_POOL_MAX = 8
+
+
+def acquire(board_size, encoding, device=None):
+    engines = _POOL.setdefault((int(board_size), encoding, str(device)), [])
+    for eng in engines:
+        if not eng._busy:
+            eng._busy = True
+            return eng
+    eng = _BoardEngine(board_size, encoding, device)
+    eng._busy = True
+    if len(engines) < _POOL_MAX:        # beyond that an engine simply lives and dies with its HexGame
+        engines.append(eng)
+    return eng
+
+
+def release(eng):
+    if eng is not None:
+        eng._busy = False

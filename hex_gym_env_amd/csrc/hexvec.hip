@@ -20,6 +20,7 @@ struct hexvec {
     bool qpb;            // fast_mode: bitboard kernels (hexvec_qpb.h); else the LDS union-find ones (hexvec_lpb.h)
     unsigned char *fast;
     size_t fast_bytes;
+    unsigned int *ticket; // hexvec_set_ticket
 };
 
 static thread_local char g_err[512] = "";
@@ -76,6 +77,7 @@ static KArgs base_args(const hexvec *h)
     a.seed_lo = (u32)h->seed;
     a.seed_hi = (u32)(h->seed >> 32);
     a.flags = h->flags;
+    a.ticket = h->ticket;
     a.T = 1;
     return a;
 }
@@ -507,6 +509,15 @@ extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
         d += E * hv::HOT_WORDS * 4;
         HV_HIP(hipMemcpyAsync(h->stats, d, E * hv::STAT_WORDS * 4, hipMemcpyDeviceToDevice, st));
     }
+    return HEXVEC_OK;
+}
+
+extern "C" int hexvec_set_ticket(hexvec_t *h, uint32_t *ticket)
+{
+    HV_HANDLE(h);
+    if (h->fast_mode)
+        return fail(HEXVEC_E_MODE, "%s", "hexvec_set_ticket: only the literal engine (NO_AUTO_RESET / EXACT_LABELS handles) signals a ticket");
+    h->ticket = ticket;
     return HEXVEC_OK;
 }
 

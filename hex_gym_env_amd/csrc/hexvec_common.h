@@ -44,6 +44,7 @@ struct KArgs {
     int cur_in;
     int phase;              // M_STEP on self-play handles: 0 whole step, 1 agent ply only, 2 opponent plies only
     unsigned char *pending; // split step: 1 = reply owed, 2 = opening owed
+    unsigned int *ticket;   // literal-engine handles: completion ticket in host-pinned memory (hexvec_set_ticket)
 };
 
 // ------------------------------------------------------------------ helpers

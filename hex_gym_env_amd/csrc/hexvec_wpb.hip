@@ -511,6 +511,12 @@ __global__ __launch_bounds__(64 * WPB) void k_hex(KArgs a)
         const int add = lane == 0 ? sr : lane == 1 ? sl : lane == 2 ? se : sw;
         st[lane] += add;
     }
+    // completion ticket (hexvec_set_ticket): every output of this board is out -- also those in host-pinned
+    // memory across the bus -- before its wavefront adds 1; the host spins on the word instead of a stream wait
+    if (a.ticket) {
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---- cold kernels: state in the reference's own layout, statistics ----

@@ -10,7 +10,7 @@ from enum import IntEnum
 import numpy as np
 
 from ._compat import gym, spaces
-from ._engine import _BoardEngine
+from . import _engine
 from .render import board_to_text
 
 
@@ -32,15 +32,23 @@ class HexGame(object):
     def __init__(self, current_player_num, board, focus_player, connected_stones=None, debug=False,
                  device=None):
         board = np.asarray(board)
-        self._eng = _BoardEngine(board.shape[1], "A", device)
+        self._eng = _engine.acquire(board.shape[1], "A", device)      # pooled: one per LIVE HexGame
         self._eng.set_position(board, connected_stones, int(current_player_num))
         self.empty_fields = int(np.count_nonzero(board == player.EMPTY))
-        self.make_move = self.make_move_debug if debug else self.fast_move
+        self._debug = bool(debug)    # (make_move dispatches on it: a bound method stored on self would be a cycle)
         self.player = focus_player
         self.done = False
         self.winner = None
         self.actions = np.arange(self.board_size ** 2)
         self._board_override = None
+
+    def __del__(self):
+        eng, self._eng = getattr(self, "_eng", None), None
+        if eng is not None:
+            try:
+                _engine.release(eng)
+            except Exception:        # interpreter shutdown
+                pass
 
     # -- attributes the reference exposes --------------------------------
     @property
@@ -69,6 +77,10 @@ class HexGame(object):
     def is_valid_move(self, action):
         y, x = self.action_to_coordinate(action)
         return self.board[y, x] == player.EMPTY
+
+    def make_move(self, action):
+        """HexGame.py:38-41: make_move is make_move_debug or fast_move, chosen at construction"""
+        return self.make_move_debug(action) if self._debug else self.fast_move(action)
 
     def make_move_debug(self, action):
         if not self.is_valid_move(action):

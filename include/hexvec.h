@@ -213,6 +213,14 @@ int hexvec_import_state(hexvec_t *h, const void *src, void *stream);
  * HexGame.make_move (HexGame.py:85-111) do exactly that, one launch + one wait per ply. */
 int hexvec_stream_synchronize(hexvec_t *h, void *stream);
 
+/* Completion ticket for callers with HOST-PINNED outputs (literal-engine handles only, HEXVEC_E_MODE otherwise):
+ * once set, every step / apply / reset / set_state launch on the handle ends with each board's wavefront adding 1 to
+ * *ticket (uint32 in host-pinned, GPU-visible memory; system-scope release behind a system fence, so all of that
+ * board's outputs are visible first).  The host then spins on *ticket == previous + num_envs instead of paying a
+ * stream wait: measured on one board, the result is visible 5.6 us after the launch call returns, the stream wait
+ * returns 9.3 us later still.  hexvec_get_state does not signal.  NULL switches the ticket off. */
+int hexvec_set_ticket(hexvec_t *h, uint32_t *ticket);
+
 /* Batched opponent / agent action sampling on the device (no handle: a stateless utility).
  * One categorical sample per row from softmax(logits[r, :]) restricted to legal[r, c] != 0 -- what
  * OpponentPolicy.choose_action gets from model.predict(board, deterministic=False, action_masks=mask)

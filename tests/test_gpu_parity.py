@@ -660,3 +660,31 @@ def test_config4_all_524288_envs_on_one_gpu_and_shard_identity(hx, lay, two):
             oo, ol, orw, od, ow = o.step()
             assert np.array_equal(_np(o2["obs"][t, :Eo]), oo), t
             assert np.array_equal(_np(o2["reward"][t, :Eo]), orw), t
+
+
+def test_completion_ticket_counts_boards_behind_their_outputs(hx):
+    """hexvec_set_ticket: every board's wavefront adds 1 to the host-pinned word behind its outputs (the single-board
+    mirrors spin on it instead of a stream wait); literal-engine handles only"""
+    import ctypes as C
+    L = hx._lib.lib()
+    n, E = 5, 7
+    env = hx.HexVecEnv(n, E, encoding="A", two_sided=True, auto_reset=False, seed=3)
+    tk = torch.zeros(1, dtype=torch.int32).pin_memory()
+    ret = torch.full((1, E), 0x55, dtype=torch.int8).pin_memory()
+    assert L.hexvec_set_ticket(env._h, C.c_void_p(tk.data_ptr())) == 0
+    acts = torch.arange(E, dtype=torch.int32, device="cuda").view(1, E).contiguous()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for k in range(1, 4):
+        ret.fill_(0x55)
+        a = (acts + 5 * (k - 1)).contiguous()
+        assert L.hexvec_apply_moves(env._h, C.c_void_p(a.data_ptr()), 1, C.c_void_p(ret.data_ptr()), None, None, None, None, st) == 0
+        for _ in range(2000000):
+            if int(tk[0]) == k * E:
+                break
+        assert int(tk[0]) == k * E
+        assert bool((ret != 0x55).all())              # the outputs were visible before the last increment
+    torch.cuda.synchronize()
+    assert L.hexvec_set_ticket(env._h, None) == 0
+    fast = hx.HexVecEnv(n, E, encoding="B")
+    rc = L.hexvec_set_ticket(fast._h, C.c_void_p(tk.data_ptr()))        # HEXVEC_E_MODE: a throughput handle
+    assert rc != 0 and b"literal engine" in L.hexvec_last_error()
