@@ -55,6 +55,12 @@ class HexSB3VecEnv(_Base):
         else:
             self.num_envs, self.observation_space, self.action_space = num_envs, obs_space, act_space
         self._tobs = torch.zeros((num_envs, n, n), dtype=torch.int8, device=self.vec.device)
+        # host side of a step: pinned staging buffers, filled by asynchronous copies behind the step's launches and
+        # awaited ONCE (a `.cpu()` per array is a blocking pageable copy each: five stream waits per step)
+        pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+        self._h_obs, self._h_legal = pin((num_envs, n, n), torch.int8), pin((num_envs, n * n), torch.uint8)
+        self._h_rew, self._h_done = pin((num_envs,), torch.float32), pin((num_envs,), torch.uint8)
+        self._h_tobs = pin((num_envs, n, n), torch.int8)
         self._actions = None
         self._ep_ret = np.zeros(num_envs, np.float64)
         self._ep_len = np.zeros(num_envs, np.int64)
@@ -66,10 +72,13 @@ class HexSB3VecEnv(_Base):
     # -- VecEnv API ---------------------------------------------------------
     def reset(self):
         obs, legal = self.sp.reset() if self.sp is not None else self.vec.reset()
-        self._masks = legal.cpu().numpy().astype(bool)
+        self._h_obs.copy_(obs.view_as(self._h_obs), non_blocking=True)
+        self._h_legal.copy_(legal, non_blocking=True)
+        torch.cuda.current_stream(self.vec.device).synchronize()
+        self._masks = self._h_legal.numpy().astype(bool)
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
-        return obs.cpu().numpy()
+        return self._h_obs.numpy().copy()
 
     def step_async(self, actions):
         self._actions = np.asarray(actions)
@@ -80,16 +89,23 @@ class HexSB3VecEnv(_Base):
             self._tobs = self.sp.terminal_obs
         else:
             obs, rew, done, legal, _ = self.vec.step(self._actions, terminal_obs=self._tobs)
-        obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
-        done_h = done.cpu().numpy().astype(bool)
-        self._masks = legal.cpu().numpy().astype(bool)
+        self._h_obs.copy_(obs.view_as(self._h_obs), non_blocking=True)
+        self._h_rew.copy_(rew, non_blocking=True)
+        self._h_done.copy_(done, non_blocking=True)
+        self._h_legal.copy_(legal, non_blocking=True)
+        self._h_tobs.copy_(self._tobs, non_blocking=True)      # (small; saves a second wait on steps that end games)
+        torch.cuda.current_stream(self.vec.device).synchronize()
+        # fresh arrays: the caller may keep the previous step's (SB3 adds `_last_obs` to its buffer after stepping)
+        obs_h, rew_h = self._h_obs.numpy().copy(), self._h_rew.numpy().copy()
+        done_h = self._h_done.numpy().astype(bool)
+        self._masks = self._h_legal.numpy().astype(bool)
         self._ep_ret += rew_h
         self._ep_len += 1
         for i in self._dirty:
             self._infos[i] = {}
         self._dirty = np.flatnonzero(done_h)
         if len(self._dirty):
-            tobs = self._tobs.cpu().numpy()
+            tobs = self._h_tobs.numpy()
             now = time.time() - self._t0
             for i in self._dirty:
                 self._infos[i] = {"terminal_observation": tobs[i].copy(), "TimeLimit.truncated": False,
