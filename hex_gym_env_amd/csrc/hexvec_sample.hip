@@ -106,15 +106,22 @@ __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int whe
 {
     const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (e >= rows) return;
-    bool sel;
-    if (when == 0) {
+    // when 3 = points 0 and 1 of the step in one launch, 4 = points 1 and 2: a board qualifies at one point at most
+    // (0 needs pending == 0, 1 pending == 2; 2 a BLACK agent, 1 after the replies a WHITE one); the second point
+    // draws under salt + 1, exactly as its own launch would
+    bool sel = false;
+    if (when == 0 || when == 3) {
         const bool d = done[e] != 0;
         ended[e] = d ? 1 : 0;
         sel = d && pending[e] == 0;
-    } else if (when == 1) {
+    }
+    if (!sel && (when == 1 || when == 3 || when == 4)) {
         sel = pending[e] == 2;
-    } else {
+        if (sel && when == 3) salt += 1u;
+    }
+    if (!sel && (when == 2 || when == 4)) {
         sel = done[e] != 0 && ended[e] == 0 && white[e] == 0;
+        if (sel && when == 4) salt += 1u;
     }
     if (!sel) return;
     const unsigned long long ctr = state[0];
@@ -156,8 +163,11 @@ extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *don
                                      uint64_t seed, uint32_t salt, int advance, unsigned long long *state2,
                                      void *stream)
 {
-    const bool ok = slot && state2 && rows >= 0 && pool_size >= 1 && when >= 0 && when <= 2 &&
-                    (when == 0 ? (done && pending && ended) : when == 1 ? pending != nullptr : (done && ended && white));
+    const bool ok = slot && state2 && rows >= 0 && pool_size >= 1 && when >= 0 && when <= 4 &&
+                    (when == 0 || when == 3 ? (done && pending && ended)
+                     : when == 1            ? pending != nullptr
+                     : when == 2            ? (done && ended && white)
+                                            : (done && pending && ended && white));
     if (!ok) {
         hv::set_error("hexvec_pick_opponents", "NULL argument or bad `when` / shape");
         return HEXVEC_E_ARG;

@@ -614,15 +614,21 @@ class VecSelfPlayEnv:
         # inside the sampler, nothing else is computed on the host side of the ABI
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
         # (all draws of the step share one device counter under salts 1..6; the last call advances it)
-        self._pick(0, salt=1)                           # BLACK agents whose game just ended: a new opponent
-        self._pick(1, salt=2)                           # fresh boards pick their opponent before it opens
+        # one launch (when = 3): BLACK agents whose game just ended get a new opponent (salt 1); fresh boards pick
+        # theirs before it opens (salt 2)
+        self._pick(3, salt=1)
         self._opponent_actions(obs, legal, pending, rng=self._rng(3))   # replies (+ openings of boards that just ended)
         out = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
-        if self._any_white:                             # openings on the boards that ended on the reply
-            self._pick(1, salt=4)
-            self._opening_actions(rng=self._rng(5), pending=self.vec.pending)
+        if self._any_white:
+            # one launch (when = 4): boards that ended on the reply -- WHITE agents' before the opening (salt 4),
+            # BLACK agents' for their next episode (salt 5).  The step's counter moves on behind it (every step must
+            # advance it, whatever the policies do); the openings then draw under the new value and a salt of their
+            # own: (counter, salt) pairs never repeat
+            self._pick(4, salt=4, advance=True)
+            self._opening_actions(rng=self._rng(6), pending=self.vec.pending)
             self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
-        self._pick(2, salt=6, advance=True)             # ended on the reply, agent BLACK
+        else:
+            self._pick(2, salt=5, advance=True)         # ended on the reply, agent BLACK
         return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
 
     def _step_general(self, actions):
@@ -665,7 +671,10 @@ class VecSelfPlayEnv:
         holder = {"captures": 0}
 
         def body():
-            a = agent_policy.choose_actions(self.vec.obs, self.vec.legal)
+            if getattr(agent_policy, "takes_row_active", False):    # our policies: draw from the step's counter (salt 7)
+                a = agent_policy.choose_actions(self.vec.obs, self.vec.legal, rng=self._rng(7))
+            else:
+                a = agent_policy.choose_actions(self.vec.obs, self.vec.legal)
             holder["actions"] = a
             self.step(a)
 

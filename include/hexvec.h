@@ -248,6 +248,8 @@ int hexvec_sample_masked(const float *logits, long long logits_row_stride, const
  *   1  before an opponent round: pending[e] == 2 (a fresh board on which the opponent is about to open,
  *      SelfplayWrapper.py:75, :79-80);
  *   2  after the opponent's replies: done[e] && !ended[e] && !white[e] (ended on the reply, agent BLACK).
+ *   3  = 0 and 1 in one launch (after the agent's ply), 4 = 1 and 2 in one launch (after the replies): a board
+ *      qualifies at one of the two points at most; the second point draws under salt + 1, as its own call would.
  * slot int64 [rows], the byte arrays uint8 [rows], all on the device; random numbers as in hexvec_sample_masked
  * (counter hash of seed, salt, draw counter, board; state2 = {draw counter, reserved}, advanced iff advance != 0). */
 int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const uint8_t *pending, uint8_t *ended,

@@ -690,8 +690,27 @@ def test_pick_opponents_kernel_selects_the_right_boards(hx):
     sel2 = (done2 != 0) & (ended == 0) & (white == 0)
     assert bool(sel2.any()) and bool((s2[~sel2] == -5).all()) and bool((s2[sel2] >= -1).all())
     assert int(state[0]) == 3                                                  # one draw counter step per call
-    assert L.hexvec_pick_opponents(p(s2), 3, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8), nbuf,
+    assert L.hexvec_pick_opponents(p(s2), 5, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8), nbuf,
                                    C.c_uint64(11), 0, 1, p(state), None) == -1       # bad `when`
+    # when = 3 / 4: two points of the step in one launch == the two launches under salts s and s + 1
+    def pick_salted(when, salt, into):
+        hx._lib.check(L.hexvec_pick_opponents(p(into), when, p(done), p(pending), p(ended), p(white), E, C.c_float(0.8),
+                                              nbuf, C.c_uint64(11), salt, 0, p(state), None))
+    pending[(white == 0) & (pending == 2)] = 0          # as in a real step: only a WHITE agent's board awaits an opening
+    for fused, first, second in ((3, 0, 1), (4, 1, 2)):
+        done = done_saved if fused == 3 else done2
+        if fused == 4:                                  # `ended` as the agent's call of this step left it
+            ended.copy_(done_saved)
+        two = torch.full((E,), -5, dtype=torch.int64, device=dev)
+        pick_salted(first, 20, two)
+        pick_salted(second, 21, two)
+        if fused == 4:
+            ended.copy_(done_saved)
+        one = torch.full((E,), -5, dtype=torch.int64, device=dev)
+        pick_salted(fused, 20, one)
+        torch.cuda.synchronize()
+        assert torch.equal(one, two) and bool((one != -5).any()), fused
+    done = done2
     # several calls may share a counter under different salts and advance it once
     before = int(state[0])
     slot_a = torch.full((E,), -5, dtype=torch.int64, device=dev)
