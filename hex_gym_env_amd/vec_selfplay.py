@@ -254,7 +254,10 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
     # -- the fused path: weights packed for hexvec_mlp_actions (include/hexvec.h) --
     def weights_version(self):
         """changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to())"""
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self.__dict__["_plist"] = list(self.parameters())   # (the module's structure is fixed)
+        return tuple([(p.data_ptr(), p._version) for p in plist])
 
     def packed_floats(self):
         from . import _lib
@@ -652,8 +655,8 @@ class VecSelfPlayEnv:
     def _pool_version(self):
         """everything host-side that a captured collection step bakes in: the pool's policy objects and
         their grouping, the evaluation flag, the 80/20 split"""
-        return (tuple(id(self.buffer.policy(k)) for k in range(-1, len(self.buffer))),
-                bool(self.buffer.evaluating), float(self.buffer.prob_best), self._any_white)
+        b = self.buffer
+        return (id(b.best), tuple(map(id, b.members)), bool(b.evaluating), float(b.prob_best), self._any_white)
 
     def capture_collect_step(self, agent_policy, warmup=3):
         """Capture  actions = agent_policy.choose_actions(obs, legal); step(actions)  as ONE hipGraph
@@ -697,18 +700,31 @@ class VecSelfPlayEnv:
 
         capture()
 
-        def sync_weights():      # packed weight tables are static buffers of the graph: refresh them on the host side
+        def sync_weights(force=False):
+            """packed weight tables and cached opening logits are static buffers of the graph: refresh them on the
+            host side when a live network changed (one tuple comparison per replay when nothing did)"""
+            uniq = holder.get("policies")
+            if uniq is None:
+                seen, uniq = set(), []
+                for pol in [agent_policy] + [self.buffer.policy(k) for k in range(-1, len(self.buffer))]:
+                    if id(pol) not in seen and hasattr(pol, "weights_version"):
+                        seen.add(id(pol))
+                        uniq.append(pol)
+                holder["policies"] = uniq
+            vers = [pol.weights_version() for pol in uniq]
+            if not force and vers == holder.get("weights"):
+                return
             tab = self._pool_table()
             if tab is not None:
                 tab.sync()
-            seen = set()
-            for pol in [agent_policy] + [self.buffer.policy(k) for k in range(-1, len(self.buffer))]:
-                if id(pol) not in seen and hasattr(pol, "sync_weights"):
-                    seen.add(id(pol))
+            for pol in uniq:
+                if hasattr(pol, "sync_weights"):
                     pol.sync_weights()
+            holder["weights"] = vers
 
         def run():
             if holder["version"] != self._pool_version():
+                holder["policies"] = None
                 capture()
             sync_weights()
             run.captures = holder["captures"]

@@ -41,12 +41,21 @@ def main():
                 r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
     sums = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     kname = {}
+    rows = []
     for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        rows += [r for r in csv.DictReader(open(f))]
+    # the board size of the bench's main workload = that of its rollout kernel; kernels of other sizes (the
+    # policy-in-the-loop leg runs 7x7) are kept apart as "<mode>@NxN"
+    sizes = [mode_of(r["Kernel_Name"]) for r in rows]
+    main_n = next((m[1] for m in sizes if m and m[3] == "rollout1"), None)
+    if main_n is None:
+        main_n = next((m[1] for m in sizes if m), None)
+    for r in rows:
+        if True:
             m = mode_of(r["Kernel_Name"])
             if not m:
                 continue
-            key = m[3]
+            key = m[3] if m[1] == main_n else "%s@%dx%d" % (m[3], m[1], m[1])
             kname[key] = "k_%s<%d,%d,%s>" % (m[0], m[1], m[2], m[3])
             acc = sums[key][r["Counter_Name"]]
             acc[0] += float(r["Counter_Value"])
