@@ -1,6 +1,7 @@
 """Diagnostic: where a wavefront of k_mlp64_mfma (32 boards) spends its cycles.
     python tools/stamp_policy.py build      (in the build container: csrc/variants/pol_stamps.so with -DHV_POL_STAMPS)
-    HEXVEC_SO=hex_gym_env_amd/csrc/variants/pol_stamps.so python tools/stamp_policy.py   (on the GPU box)"""
+    HEXVEC_MLP_NOSPLIT=1 HEXVEC_SO=hex_gym_env_amd/csrc/variants/pol_stamps.so python tools/stamp_policy.py   (on the GPU
+    box; the stamps are in k_mlp64_mfma, the one-wavefront-per-tile kernel)"""
 import ctypes as C
 import os
 import subprocess
