@@ -218,6 +218,43 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         # the fused libhexvec call serves the SB3-default shape family; anything else keeps the torch spelling
         self.fusable = len(self.hidden) == 2 and all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
         self._packed = self._packed_version = None
+        self._compute_device = None     # None: where the parameters live; view_of_sb3() names the env's GPU
+        self._owner = None
+
+    @classmethod
+    def view_of_sb3(cls, model, device, deterministic=False, generator=None):
+        """LIVE view of the actor of an SB3 / sb3_contrib model with an MLP policy (what the reference's
+        OpponentPolicy wraps, SelfplayWrapper.py:26-35): the same nn.Linear objects, no copy -- the model may keep
+        training and may live on the CPU; the packed weights on `device` follow its parameter versions.  Raises
+        TypeError if the policy is not  flatten -> Linear-Tanh-Linear-Tanh -> Linear  (then predict() is used)."""
+        pol = getattr(model, "policy", None)
+        ext, act = getattr(pol, "mlp_extractor", None), getattr(pol, "action_net", None)
+        pnet = getattr(ext, "policy_net", None)
+        if pnet is None or not isinstance(act, torch.nn.Linear):
+            raise TypeError("not an actor-critic MLP policy")
+        fe = getattr(pol, "features_extractor", None)
+        if fe is not None and type(fe).__name__ not in ("FlattenExtractor", "Flatten"):
+            raise TypeError("the policy has a feature extractor other than flatten")
+        mods = list(pnet)
+        lins = [m for m in mods if isinstance(m, torch.nn.Linear)]
+        if len(lins) != 2 or len(mods) != 4 or not all(isinstance(m, torch.nn.Tanh) for m in mods[1::2]):
+            raise TypeError("the actor is not Linear-Tanh-Linear-Tanh")
+        if act.in_features != lins[1].out_features or act.out_features != lins[0].in_features:
+            raise TypeError("the actor does not map the board to one logit per cell")
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        self.policy_net, self.action_net = pnet, act            # shared modules: live weights
+        self.deterministic, self.generator = deterministic, generator
+        self.n_cells, self.hidden = int(lins[0].in_features), (int(lins[0].out_features), int(lins[1].out_features))
+        self.fusable = all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
+        self._packed = self._packed_version = None
+        self._compute_device = torch.device(device)
+        self._owner = model
+        return self
+
+    @property
+    def compute_device(self):
+        return self._compute_device if self._compute_device is not None else self.action_net.weight.device
 
     @classmethod
     def from_state_dict(cls, sd, **kw):
@@ -247,8 +284,9 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
 
     @torch.no_grad()
     def logits(self, obs, legal):
-        x = obs.reshape(obs.shape[0], -1).float()
-        z = self.action_net(self.policy_net(x))
+        """masked logits by plain torch ops (fp32 reference of the fused kernel), on the device of obs"""
+        x = obs.reshape(obs.shape[0], -1).float().to(self.action_net.weight.device)
+        z = self.action_net(self.policy_net(x)).to(obs.device)
         return z.masked_fill(legal == 0, float("-inf"))
 
     # -- the fused path: weights packed for hexvec_mlp_actions (include/hexvec.h) --
@@ -271,9 +309,10 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         from . import _lib
         l1, l2 = [m for m in self.policy_net if isinstance(m, torch.nn.Linear)]
         src = [t.detach() for t in (l1.weight, l1.bias, l2.weight, l2.bias, self.action_net.weight, self.action_net.bias)]
-        if not dst.is_cuda or any(t.device != dst.device for t in src):
-            raise RuntimeError("pack_into: the network and dst must live on the same GPU (libhexvec has no CPU path)")
-        src = [t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous() for t in src]
+        if not dst.is_cuda:
+            raise RuntimeError("pack_into: dst must live on a GPU (libhexvec has no CPU path)")
+        # (a model that lives on the CPU or another GPU is copied over: 6 small tensors, only when it changed)
+        src = [t.to(device=dst.device, dtype=torch.float32).contiguous() for t in src]
         if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() != self.packed_floats():
             raise ValueError("dst is not a contiguous float32 tensor of packed_floats() elements")
         _lib.check(_lib.lib().hexvec_mlp_pack(*[C.c_void_p(t.data_ptr()) for t in src], self.n_cells, self.hidden[0],
@@ -282,10 +321,10 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         return dst
 
     def packed(self):
-        """the packed weights on the parameters' device, re-packed when the parameters changed"""
+        """the packed weights on the compute device, re-packed when the parameters changed"""
         v = self.weights_version()
-        if self._packed is None or self._packed.device != self.action_net.weight.device:
-            self._packed = torch.empty(self.packed_floats(), dtype=torch.float32, device=self.action_net.weight.device)
+        if self._packed is None or self._packed.device != self.compute_device:
+            self._packed = torch.empty(self.packed_floats(), dtype=torch.float32, device=self.compute_device)
             self._packed_version = None
         if self._packed_version != v:
             self.pack_into(self._packed)
@@ -298,12 +337,12 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         network.  Cached in a static buffer and recomputed only when the parameters changed -- a self-play step
         samples openings from it without running the network."""
         v = self.weights_version()
-        dev = self.action_net.weight.device
+        dev, pdev = self.compute_device, self.action_net.weight.device
         if getattr(self, "_open_logits", None) is None or self._open_logits.device != dev:
             self._open_logits = torch.empty((1, self.n_cells), dtype=torch.float32, device=dev)
             self._open_version = None
-        if self._open_version != v:
-            self._open_logits.copy_(self.action_net(self.policy_net(torch.zeros((1, self.n_cells), device=dev))))
+        if self._open_version != v:     # (evaluated where the parameters live, kept on the compute device)
+            self._open_logits.copy_(self.action_net(self.policy_net(torch.zeros((1, self.n_cells), device=pdev))))
             self._open_version = v
         return self._open_logits
 
@@ -322,11 +361,13 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         if self.deterministic:
             a = self.logits(obs, legal).argmax(1).to(torch.int32)
             return a if out is None else out.copy_(a)
-        x = obs.reshape(obs.shape[0], -1).float()
-        return sample_masked(self.action_net(self.policy_net(x)), legal, self.generator,
+        x = obs.reshape(obs.shape[0], -1).float().to(self.action_net.weight.device)
+        return sample_masked(self.action_net(self.policy_net(x)).to(legal.device), legal, self.generator,
                              self.bad_rows_counter(legal.device), row_active, out, rng)
 
     def save_model(self, path):
+        if self._owner is not None:     # a view of an SB3 model: OpponentPolicy.save_model (SelfplayWrapper.py:37-38)
+            return self._owner.save(path)
         torch.save(self.state_dict(), path)
 
 
@@ -349,11 +390,18 @@ class PredictAdapter:
         self.opponent_model.save(path)
 
 
-def as_policy(model):
-    """device policy for whatever set_opponent_model() is given"""
+def as_policy(model, device=None):
+    """device policy for whatever set_opponent_model() is given: a policy of this module as is; an SB3-style model
+    whose actor is the default MLP as a LIVE view on the fused kernel (MlpActorPolicy.view_of_sb3); any other model
+    with predict() through PredictAdapter (batched numpy calls on the host)"""
     if hasattr(model, "choose_actions"):
         return model
     if hasattr(model, "predict"):
+        if device is not None and torch.device(device).type == "cuda":
+            try:
+                return MlpActorPolicy.view_of_sb3(model, device)
+            except TypeError:
+                pass
         return PredictAdapter(model)
     raise TypeError("an opponent needs choose_actions(obs, legal) or predict(obs, deterministic, action_masks)")
 
@@ -386,7 +434,7 @@ class _PoolTable:
         first = by_slot[0]
         return all(isinstance(p, MlpActorPolicy) and p.fusable and p.n_cells == first.n_cells
                    and p.hidden == first.hidden and bool(p.deterministic) == bool(first.deterministic)
-                   and p.action_net.weight.device == torch.device(device) for p in by_slot)
+                   and p.compute_device == torch.device(device) for p in by_slot)
 
     def sync(self):
         for u, pol in enumerate(self.policies):
@@ -417,7 +465,7 @@ class VecSelfPlayEnv:
             pool = [RandomLegalPolicy(self._gen) for _ in range(buffer_size)]
             self.buffer = OpponentBuffer(pool, np.zeros(buffer_size), RandomLegalPolicy(self._gen), prob_best)
         else:                            # :54-57: the given model in every slot
-            base_model = as_policy(base_model)
+            base_model = as_policy(base_model, self.device)
             pool = [base_model for _ in range(buffer_size)]
             self.buffer = OpponentBuffer(pool, np.zeros(buffer_size) if scores is None else scores,
                                          base_model, prob_best)
@@ -765,7 +813,7 @@ class VecSelfPlayEnv:
         return self.buffer.best_mean_reward
 
     def set_opponent_model(self, index, model, score):
-        self.buffer.replace(index, as_policy(model), score)
+        self.buffer.replace(index, as_policy(model, self.device), score)
 
     def save_best_model(self, path=None):
         self.buffer.save_best(path)
