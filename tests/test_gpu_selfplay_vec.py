@@ -451,7 +451,7 @@ def _bench_under_launcher(nranks):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(29500 + 17 * nranks),
            os.path.join(root, "bench.py"), "--gpus", str(nranks), "--steps", "20", "--warmup", "5",
-           "--envs", "8192", "--no-cpu", "--no-host-stepped", "--no-w2"]
+           "--envs", "8192", "--no-cpu", "--no-host-stepped", "--no-w2", "--no-collect"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

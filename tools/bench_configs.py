@@ -14,7 +14,7 @@ steps = sys.argv[1] if len(sys.argv) > 1 else "200"
 for n, e in ((7, 32768), (13, 16384), (13, 65536), (11, 65536)):
     for lay in ("rollout", "bitboard"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--board", str(n), "--envs", str(e), "--steps", steps,
-               "--warmup", "5", "--no-cpu", "--layout", lay]
+               "--warmup", "5", "--no-cpu", "--no-collect", "--layout", lay]
         if lay == "bitboard":
             cmd += ["--no-host-stepped"]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
