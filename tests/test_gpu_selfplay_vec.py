@@ -437,6 +437,9 @@ def test_bench_json_contract():
     assert abs(r["obs_only_frac"] - r["frac"] * 121 / 251) < 1e-9 and r["kernel"].startswith("k_lpb") and d["host_stepped"]["kernel"].startswith("k_qpb")
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    cs = d["collect_step"]                  # BASELINE config 3 with the policy in the loop (secondary entry)
+    assert "error" not in cs and cs["us_per_step"] > 0 and cs["degenerate_rows"] == 0
+    assert abs(cs["agent_steps_per_s"] - 32768 / (cs["us_per_step"] * 1e-6)) / cs["agent_steps_per_s"] < 1e-9
 
 
 def _bench_under_launcher(nranks):
