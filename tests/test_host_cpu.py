@@ -128,3 +128,19 @@ def test_minihex_alias_package_has_the_reference_module_names():
     assert m.random_policy(board) != 4                     # never the occupied cell
     assert callable(selfplay_wrapper) and BaseRandomPolicy().save_model("x") is None
     assert EnvA is not EnvB and HexGame is not None and OpponentPolicy is not None
+
+
+def test_committed_profile_matches_the_drivers_command():
+    """bench.py fills roofline.traffic / on_chip from profiles/<round>/bench_pmc_summary.json only if that profile was
+    taken with the same board / envs / steps per launch: the committed one must be the driver's command"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    rnd = src.split('PROFILE_ROUND = "')[1].split('"')[0]
+    d = json.load(open(os.path.join(root, "profiles", rnd, "bench_pmc_summary.json")))
+    assert d["config"] == {"board": 11, "envs": 65536, "steps_per_launch": 20}
+    c = d["counters"]["rollout1"]
+    for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+        assert c[k] > 0, k
+    assert d["kernel"].startswith("k_lpb")

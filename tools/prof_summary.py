@@ -32,6 +32,13 @@ def main():
     if "--config" in sys.argv:
         b, e, t = (int(x) for x in sys.argv[sys.argv.index("--config") + 1].split(","))
         cfg = {"board": b, "envs": e, "steps_per_launch": t}
+    if cfg is None and os.path.exists(os.path.join(d, "trace.json")):   # the bench line of the trace pass names it
+        try:
+            line = [l for l in open(os.path.join(d, "trace.json")) if l.startswith("{")][-1]
+            c = json.loads(line)["config"]
+            cfg = {"board": c["board_size"], "envs": c["envs_per_gpu"], "steps_per_launch": c["steps_per_launch"]}
+        except Exception:
+            cfg = None
     stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
     report = []
     if stats:
