@@ -398,8 +398,15 @@ def as_policy(model, device=None):
         return model
     if hasattr(model, "predict"):
         if device is not None and torch.device(device).type == "cuda":
+            # one view per (model, device): the reference's callback hands the SAME live model to slot after slot
+            # (EvaluationCallback.py:45-49), and slots that share a policy object share a network in the pool table
+            views = model.__dict__.setdefault("_hexvec_views", {}) if hasattr(model, "__dict__") else {}
+            key = str(torch.device(device))
+            if key in views:
+                return views[key]
             try:
-                return MlpActorPolicy.view_of_sb3(model, device)
+                views[key] = MlpActorPolicy.view_of_sb3(model, device)
+                return views[key]
             except TypeError:
                 pass
         return PredictAdapter(model)

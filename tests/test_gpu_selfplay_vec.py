@@ -940,6 +940,8 @@ def test_sb3_style_models_run_on_the_fused_kernel_as_live_views(hx):
     assert float((lg - ref - 1.0).abs().max()) < 2e-5
     v1.save_model("somewhere")
     assert m1.saved == "somewhere"
+    env.set_opponent_model(3, m1, 4.0)                   # the same live model again: the same view, still two networks
+    assert env.buffer.policy(3) is v1 and len(env._pool_table().policies) == 2
     # a different architecture: predict() adapter
     odd = _FakeSb3Model(n * n, hidden=(64, 64, 64))
     assert isinstance(as_policy(odd, "cuda"), PredictAdapter)
