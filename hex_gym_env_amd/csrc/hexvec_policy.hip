@@ -936,15 +936,20 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
         lds = 2 * ((64 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * POL_WAVES + 1);
         fn = (const void *)k_mlp_actions;
     }
-    static thread_local size_t lds_allowed[3] = {0, 0, 0};
+    // more dynamic LDS than the default limit must be allowed per kernel AND per device: remembered per
+    // (device, kernel) of this thread
+    static thread_local size_t lds_allowed[16][3] = {};
     const int which = mfma ? (split ? 2 : 1) : 0;
-    if (lds > lds_allowed[which]) {
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    size_t &allowed = lds_allowed[cur_dev & 15][which];
+    if (lds > 48 * 1024 && lds > allowed) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_error("hexvec_mlp_actions", hipGetErrorString(e));
             return HEXVEC_E_HIP;
         }
-        lds_allowed[which] = lds;
+        allowed = lds;
     }
     if (mfma && split) // one tile of 32 boards per workgroup of two wavefronts
         hipLaunchKernelGGL(k_mlp64_mfma2, dim3(2 * tiles), dim3(128), lds, st, a);

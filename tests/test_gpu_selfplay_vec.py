@@ -736,7 +736,7 @@ def _random_position(rows, cells, seed):
 @pytest.mark.parametrize("n,hidden,rows", [(5, (64, 64), 1000), (7, (64, 64), 4096), (11, (64, 64), 777),
                                            (14, (64, 64), 500), (19, (64, 64), 200), (4, (64, 64), 33),      # matrix cores
                                            (2, (64, 64), 70), (3, (64, 64), 2100), (9, (64, 64), 40000),
-                                           (5, (64, 64), 60000), (11, (64, 64), 66000),                      # one wavefront per tile
+                                           (5, (64, 64), 60000), (11, (64, 64), 66000), (19, (64, 64), 52000),  # one wavefront per tile (19x19: 92 KB of LDS)
                                            (13, (32, 48), 300), (19, (128, 64), 130), (4, (16, 16), 65),     # general widths
                                            (7, (64, 32), 640)])
 def test_fused_actor_matches_fp32_torch_forward(hx, n, hidden, rows):
