@@ -105,12 +105,14 @@ class HexSB3VecEnv(_Base):
             self._infos[i] = {}
         self._dirty = np.flatnonzero(done_h)
         if len(self._dirty):
-            tobs = self._h_tobs.numpy()
+            # one gather for all finished boards, then one dict per finished board (the VecEnv contract wants dicts)
+            tobs = self._h_tobs.numpy()[self._dirty]
             now = time.time() - self._t0
-            for i in self._dirty:
-                self._infos[i] = {"terminal_observation": tobs[i].copy(), "TimeLimit.truncated": False,
-                                  "episode": {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]),
-                                              "t": now}}
+            rets, lens = self._ep_ret[self._dirty].tolist(), self._ep_len[self._dirty].tolist()
+            infos = self._infos
+            for k, i in enumerate(self._dirty.tolist()):
+                infos[i] = {"terminal_observation": tobs[k], "TimeLimit.truncated": False,
+                            "episode": {"r": rets[k], "l": lens[k], "t": now}}
             self._ep_ret[self._dirty] = 0
             self._ep_len[self._dirty] = 0
         return obs_h, rew_h, done_h, self._infos
