@@ -57,6 +57,12 @@
 // stamp exists in the product build.
 #ifdef HV_STAMPS
 __device__ unsigned long long g_stamps[4096][12];
+__device__ unsigned long long g_phase[4096][4]; // s_memrealtime (100 MHz, one clock for the whole chip) at kernel entry / state in LDS / before the store-back / stores retired
+#define HV_PHASE(blk, k)                                                                   \
+    do {                                                                                   \
+        __builtin_amdgcn_s_waitcnt(0);                                                     \
+        if (lane == 0 && (blk) < 4096) g_phase[blk][k] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 struct StampBox {
     unsigned long long acc[4], prev;
 };
@@ -86,6 +92,7 @@ struct StampBox {
 #else
 struct StampBox {
 };
+#define HV_PHASE(blk, k) do { } while (0)
 #define HV_STAMP_INIT() do { } while (0)
 #define HV_MARK(k) do { } while (0)
 #define HV_PMARK0(box) do { } while (0)
@@ -591,6 +598,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         }
     };
 
+    HV_PHASE(blk, 0);
     LS s;
     s.key = mix32(((u32)env + a.env_offset) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi;
     if (MODE == M_RESET && a.init) {
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.sw = (int)r[7 * 64 + lane];
     }
 
+    HV_PHASE(blk, 1);
     if (L::ONE) agent1 = __ballot(live && s.agent != 0);
     s.kc = s.key + s.ctr * 0x9E3779B9U;
 
@@ -911,6 +920,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     }
 
     emit_release();
+    HV_PHASE(blk, 2);
     // state back to HBM
     {   // eight 1 KB pieces per trip: the LDS reads of a trip are issued together, then its stores
         constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
@@ -946,6 +956,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     r[5 * 64 + lane] = (u32)s.sl;
     r[6 * 64 + lane] = (u32)s.se;
     r[7 * 64 + lane] = (u32)s.sw;
+    HV_PHASE(blk, 3);
 }
 
 // ---- cold kernels on the fast state ----
@@ -1098,6 +1109,10 @@ hipError_t HV_LPB_NAME(stats)(const unsigned char *fast, int N, int enc, int two
 extern "C" int hexvec_debug_stamps(unsigned long long *host_dst, int nblocks)
 {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), (size_t)nblocks * 12 * sizeof(unsigned long long));
+}
+extern "C" int hexvec_debug_phases(unsigned long long *host_dst, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_phase), (size_t)nblocks * 4 * sizeof(unsigned long long));
 }
 #endif
 

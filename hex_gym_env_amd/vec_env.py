@@ -115,6 +115,13 @@ class HexVecEnv:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
         return a
 
+    def _tobs(self, t):
+        """a caller's terminal-observation buffer: int8 [E, N, N] on this device (written by the kernels)"""
+        if t is not None and (t.dtype != torch.int8 or t.numel() != self.num_envs * self.cells
+                              or t.device != self.device or not t.is_contiguous()):
+            raise ValueError("terminal_obs must be a contiguous int8 [E, N, N] tensor on the env's device")
+        return t
+
     # ------------------------------------------------------------------
     def reset(self, env_mask=None, opp_actions=None):
         """reset() of the masked envs (all by default) -> (obs int8 [E,N,N], legal uint8 [E,N*N])."""
@@ -137,9 +144,7 @@ class HexVecEnv:
         """
         a = self._i32(actions, (self.num_envs,))
         o = self._i32(opp_actions, (self.num_envs,))
-        if terminal_obs is not None and (terminal_obs.dtype != torch.int8
-                                         or terminal_obs.numel() != self.num_envs * self.cells):
-            raise ValueError("terminal_obs must be int8 [E, N, N]")
+        self._tobs(terminal_obs)
         _lib.check(self._L.hexvec_step(self._h, _p(a), _p(o), _p(self.obs), _p(self.legal),
                                        _p(self.reward), _p(self.done), _p(self.winner),
                                        _p(terminal_obs), self._stream()))
@@ -153,6 +158,7 @@ class HexVecEnv:
         that were reset with the opponent to move first).  reward / done / winner are complete
         after the last call."""
         a = self._i32(actions, (self.num_envs,))
+        self._tobs(terminal_obs)
         _lib.check(self._L.hexvec_step_agent(self._h, _p(a), _p(self.obs), _p(self.legal),
                                              _p(self.reward), _p(self.done), _p(self.winner),
                                              _p(terminal_obs), _p(self.pending), self._stream()))
@@ -162,6 +168,7 @@ class HexVecEnv:
         """Split step, second half: the opponent's ply on every pending board
         -> (obs, reward, done, legal, winner, pending)."""
         o = self._i32(opp_actions, (self.num_envs,))
+        self._tobs(terminal_obs)
         _lib.check(self._L.hexvec_step_opponent(self._h, _p(o), _p(self.obs), _p(self.legal),
                                                 _p(self.reward), _p(self.done), _p(self.winner),
                                                 _p(terminal_obs), _p(self.pending), self._stream()))
@@ -191,6 +198,19 @@ class HexVecEnv:
                 actions=torch.empty((T, E), dtype=torch.int32, device=dev),
                 reward=torch.empty((T, E), dtype=torch.float32, device=dev),
                 done=torch.empty((T, E), dtype=torch.uint8, device=dev))
+        # the kernels write T rows into whatever they are handed: a short, misplaced or mistyped buffer must raise
+        # here, not fault the GPU
+        want = {"obs": ((T, E, Cc), torch.int8), "legal": ((T, E, Cc), torch.uint8), "actions": ((T, E), torch.int32),
+                "reward": ((T, E), torch.float32), "done": ((T, E), torch.uint8)}
+        for k, t in out.items():
+            if t is None:
+                continue
+            if k not in want:
+                raise KeyError(f"unknown rollout output {k!r}")
+            shape, dt = want[k]
+            if (t.dtype != dt or t.device != dev or not t.is_contiguous() or t.numel() < T * E * (Cc if len(shape) == 3 else 1)):
+                raise ValueError(f"rollout output {k!r} must be a contiguous {dt} tensor on {dev} with at least "
+                                 f"{shape} elements, got {tuple(t.shape)} {t.dtype} on {t.device}")
         _lib.check(fn(self._h, T, _p(out.get("obs")), _p(out.get("legal")), _p(out.get("actions")),
                       _p(out.get("reward")), _p(out.get("done")), self._stream()))
         return out

@@ -688,3 +688,21 @@ def test_completion_ticket_counts_boards_behind_their_outputs(hx):
     fast = hx.HexVecEnv(n, E, encoding="B")
     rc = L.hexvec_set_ticket(fast._h, C.c_void_p(tk.data_ptr()))        # HEXVEC_E_MODE: a throughput handle
     assert rc != 0 and b"literal engine" in L.hexvec_last_error()
+
+
+def test_rollout_outputs_are_checked_before_the_launch(hx):
+    """a rollout writes T rows into the caller's buffers: too short, wrong dtype or a CPU tensor raises in the host
+    layer (the library itself sees raw pointers)"""
+    env = hx.HexVecEnv(5, 256, encoding="B", seed=1)
+    good = env.rollout_selfplay(4)
+    assert good["obs"].shape == (4, 256, 25)
+    with pytest.raises(ValueError):
+        env.rollout_selfplay(8, good)                                    # buffers hold 4 rows
+    with pytest.raises(ValueError):
+        env.rollout_selfplay(4, dict(good, reward=good["reward"].double()))
+    with pytest.raises(ValueError):
+        env.rollout_selfplay(4, dict(good, done=good["done"].cpu()))
+    with pytest.raises(KeyError):
+        env.rollout_selfplay(4, dict(good, winner=good["done"]))
+    env.rollout_selfplay(4, {"obs": good["obs"]})                        # a subset is fine
+    env.rollout_selfplay(2, good)                                        # so is a larger buffer

@@ -13,7 +13,8 @@ CSRC = os.path.join(ROOT, "hex_gym_env_amd", "csrc")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     os.makedirs(os.path.join(CSRC, "variants"), exist_ok=True)
     objs = []
-    for f in ("hexvec", "hexvec_wpb", "hexvec_qpb_s", "hexvec_qpb_m", "hexvec_qpb_l", "hexvec_qpb_x", "hexvec_lpb64"):
+    for f in ("hexvec", "hexvec_sample", "hexvec_policy", "hexvec_wpb", "hexvec_qpb_s", "hexvec_qpb_m", "hexvec_qpb_l", "hexvec_qpb_x",
+              "hexvec_lpb64"):
         o = os.path.join(CSRC, f + ".o")
         if f == "hexvec_lpb64":
             o = os.path.join(CSRC, "variants", "lpb64_stamps.o")
@@ -52,3 +53,24 @@ print("s_memtime ticks (shader cycles; the stamps themselves add ~15 %%) per ste
 for n, v in zip(names, per):
     print("  %-62s %8.1f" % (n, v))
 print("  %-45s %8.1f" % ("total", per[:8].sum()))
+
+# launch phases (s_memtime at kernel entry / state in LDS / before the store-back / stores retired), per workgroup
+T2 = int(os.environ.get("T", 20))
+out2 = {k: torch.empty((T2,) + tuple(v.shape[1:]), dtype=v.dtype, device="cuda") for k, v in out.items()}
+for _ in range(5):
+    env.rollout_selfplay(T2, out2)
+torch.cuda.synchronize()
+ph = np.zeros((nb, 4), np.uint64)
+assert L.hexvec_debug_phases(ph.ctypes.data_as(C.c_void_p), nb) == 0
+ph = ph.astype(np.float64)
+ph = ph[(ph > 0).all(1)]
+print("(%d of %d workgroups carry all four stamps)" % (len(ph), nb))
+span = ph[:, 3].max() - ph[:, 0].min()
+print("launch of %d steps: first workgroup in to last out %.0f ticks of 10 ns; per workgroup (mean): state load %.0f, steps %.0f, "
+      "store-back %.0f; entry spread %.0f, exit spread %.0f"
+      % (T2, span, (ph[:, 1] - ph[:, 0]).mean(), (ph[:, 2] - ph[:, 1]).mean(), (ph[:, 3] - ph[:, 2]).mean(),
+         ph[:, 0].max() - ph[:, 0].min(), ph[:, 3].max() - ph[:, 3].min()))
+q = np.percentile
+print("   entry times relative to the first: p50 %.0f p90 %.0f p99 %.0f; exit times relative to the last: p50 %.0f p10 %.0f p1 %.0f"
+      % (q(ph[:, 0], 50) - ph[:, 0].min(), q(ph[:, 0], 90) - ph[:, 0].min(), q(ph[:, 0], 99) - ph[:, 0].min(),
+         ph[:, 3].max() - q(ph[:, 3], 50), ph[:, 3].max() - q(ph[:, 3], 10), ph[:, 3].max() - q(ph[:, 3], 1)))
