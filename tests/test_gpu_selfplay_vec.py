@@ -836,19 +836,24 @@ def test_fused_actor_serves_a_pool_of_networks_in_one_call(hx):
         mlp_actions(table[:, :-16].contiguous(), C_, 64, 64, obs, legal)
 
 
-def test_vec_selfplay_pool_of_distinct_networks_is_one_launch_per_round(hx):
+@pytest.mark.parametrize("mode", ["train", "eval", "sample_board"])
+def test_vec_selfplay_pool_of_distinct_networks_is_one_launch_per_round(hx, mode):
     """VecSelfPlayEnv with a pool of DISTINCT actor networks: the weights-table path (one policy launch per
     opponent round) plays exactly what the per-policy grouped path plays (arg-max opponents: no random draws
-    to line up), and keeps following pool updates"""
+    to line up), and keeps following pool updates -- in the training step, in evaluation mode (the pool is walked in
+    order, SelfplayWrapper.py:92-96) and with sampled start positions (sample_board)"""
     from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
     n, E = 5, 2048
     torch.manual_seed(1)
     nets = [MlpActorPolicy(n * n, deterministic=True).cuda() for _ in range(4)]
 
     def make(fused):
-        env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=6, base_model=nets[0], seed=4)
+        env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=6, base_model=nets[0], seed=4,
+                             sample_board=mode == "sample_board")
         for k in range(6):
             env.set_opponent_model(k, nets[k % 4], float(k))
+        if mode == "eval":
+            env.set_eval(True)
         if not fused:
             env._pool_table = lambda: None
         return env
