@@ -16,6 +16,7 @@ RandomLegalPolicy (BaseRandomPolicy, :16-24) and MlpActorPolicy (an SB3 Maskable
 actor, loadable from the reference's shipped checkpoints with weights_only=True).
 """
 import io
+import weakref
 import zipfile
 
 import numpy as np
@@ -249,7 +250,7 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         self.fusable = all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
         self._packed = self._packed_version = None
         self._compute_device = torch.device(device)
-        self._owner = model
+        self._owner = weakref.ref(model)        # (weak: the view is cached per model, see as_policy)
         return self
 
     @property
@@ -366,8 +367,9 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
                              self.bad_rows_counter(legal.device), row_active, out, rng)
 
     def save_model(self, path):
-        if self._owner is not None:     # a view of an SB3 model: OpponentPolicy.save_model (SelfplayWrapper.py:37-38)
-            return self._owner.save(path)
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:           # a view of an SB3 model: OpponentPolicy.save_model (SelfplayWrapper.py:37-38)
+            return owner.save(path)
         torch.save(self.state_dict(), path)
 
 
@@ -390,6 +392,9 @@ class PredictAdapter:
         self.opponent_model.save(path)
 
 
+_LIVE_VIEWS = weakref.WeakKeyDictionary()     # SB3-style model -> {device: MlpActorPolicy view}
+
+
 def as_policy(model, device=None):
     """device policy for whatever set_opponent_model() is given: a policy of this module as is; an SB3-style model
     whose actor is the default MLP as a LIVE view on the fused kernel (MlpActorPolicy.view_of_sb3); any other model
@@ -400,7 +405,11 @@ def as_policy(model, device=None):
         if device is not None and torch.device(device).type == "cuda":
             # one view per (model, device): the reference's callback hands the SAME live model to slot after slot
             # (EvaluationCallback.py:45-49), and slots that share a policy object share a network in the pool table
-            views = model.__dict__.setdefault("_hexvec_views", {}) if hasattr(model, "__dict__") else {}
+            # (kept beside the model, not on it: an SB3 model serialises its __dict__ when it is saved)
+            try:
+                views = _LIVE_VIEWS.setdefault(model, {})
+            except TypeError:            # a model that cannot be weakly referenced: no sharing
+                views = {}
             key = str(torch.device(device))
             if key in views:
                 return views[key]
