@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64 * POL_WAVES) void k_mlp_actions(MlpArgs a)
     const u64 vmask = __ballot(r >= 0); // the same in every wavefront of the workgroup
     if (vmask == 0) return;
     const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
-    const int p = rfl(policy_key(a, r0)); // grouped launches: one network per tile
+    // grouped launches: one network per tile; with ONE network nothing about the weights waits for the loads above
+    const int p = (a.slot && a.n_policies > 1) ? rfl(policy_key(a, r0)) : 0;
     const float *__restrict__ wp = a.weights + (size_t)p * (size_t)a.sh.stride;
 
     // LDS: obs bytes [64][cells] | legal bytes [64][cells] | hA [h1][64] | hB [h2][64] | reduction [W][64] x 3 | rows [64]
@@ -298,6 +299,17 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int cells = a.ms.cells, T1 = a.ms.T1;
 
     POL_MARK(0);
+    // Weights: one coalesced 256-byte record per MFMA, streamed from L2 into registers a whole stage AHEAD of the
+    // MFMAs that use them (layer 2's records and layer 1's first chunk are requested here, before the boards'
+    // rows; the first output tiles' before layer 2 runs, ...): with one wavefront per SIMD nothing else hides the
+    // L2 latency.  With ONE network they are requested before anything else is known about the tile.
+    const bool one_net = !(a.slot && a.n_policies > 1);
+    const float *__restrict__ wl = a.weights + lane;
+    float w2r[66], wa[32], wb[32];
+    if (one_net) {
+        wload(wa, wl);
+        wload(w2r, wl + a.ms.o_w2);
+    }
     const int pos = tile * 32 + b;
     int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
     if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) { // nobody asked for this board's action
@@ -306,18 +318,12 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
     }
     const u64 vmask = __ballot(r >= 0);
     if (vmask == 0) return; // wavefronts are independent: no workgroup barrier anywhere in this kernel
-    const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
-    const int p = rfl(policy_key(a, r0)); // grouped launches: one network per tile
-    const float *__restrict__ wp = a.weights + (size_t)p * (size_t)a.ms.stride;
-
-    // Weights: one coalesced 256-byte record per MFMA, streamed from L2 into registers a whole stage AHEAD of the
-    // MFMAs that use them (layer 2's records and layer 1's first chunk are requested here, before the boards'
-    // rows; the first output tiles' before layer 2 runs, ...): with one wavefront per SIMD nothing else hides the
-    // L2 latency.
-    const float *__restrict__ wl = wp + lane;
-    float w2r[66], wa[32], wb[32];
-    wload(wa, wl);
-    wload(w2r, wl + a.ms.o_w2);
+    if (!one_net) { // grouped launches: one network per tile
+        const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
+        wl += (size_t)rfl(policy_key(a, r0)) * (size_t)a.ms.stride;
+        wload(wa, wl);
+        wload(w2r, wl + a.ms.o_w2);
+    }
 
     // this wavefront's observation and mask rows -> LDS [32][cells] bytes each (a row is contiguous in HBM)
     const int img = (32 * cells + 15) & ~15;
@@ -496,6 +502,23 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     if (a.ntiles && tile >= 2 * *a.ntiles) return; // (workgroup-uniform, like every exit below)
     const int cells = a.ms.cells, T1 = a.ms.T1;
 
+    // this wavefront's records: layer 2 (33) and the first 16 steps of layer 1, requested before the boards' rows --
+    // with ONE network before anything else is known about the tile
+    const bool one_net = !(a.slot && a.n_policies > 1);
+    const float *__restrict__ wl = a.weights + lane;
+    float w2r[33], wa[16], wb[16];
+    auto wload1 = [&](float(&dst)[16], int t0) { // records (t, tile w), t = t0 .. t0 + 15
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[i] = wl[(size_t)((t0 + i) * 2 + w) * 64];
+    };
+    auto wload2 = [&]() {
+#pragma unroll
+        for (int s = 0; s < 33; ++s) w2r[s] = wl[a.ms.o_w2 + (size_t)(s * 2 + w) * 64];
+    };
+    if (one_net) {
+        wload1(wa, 0);
+        wload2();
+    }
     const int pos = tile * 32 + b;
     int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
     if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) {
@@ -504,19 +527,12 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     }
     const u64 vmask = __ballot(r >= 0);
     if (vmask == 0) return;
-    const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
-    const int p = rfl(policy_key(a, r0));
-    const float *__restrict__ wl = a.weights + (size_t)p * (size_t)a.ms.stride + lane;
-
-    // this wavefront's records: layer 2 (33) and the first 16 steps of layer 1, requested before the boards' rows
-    float w2r[33], wa[16], wb[16];
-    auto wload1 = [&](float(&dst)[16], int t0) { // records (t, tile w), t = t0 .. t0 + 15
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = wl[(size_t)((t0 + i) * 2 + w) * 64];
-    };
-    wload1(wa, 0);
-#pragma unroll
-    for (int s = 0; s < 33; ++s) w2r[s] = wl[a.ms.o_w2 + (size_t)(s * 2 + w) * 64];
+    if (!one_net) {
+        const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
+        wl += (size_t)rfl(policy_key(a, r0)) * (size_t)a.ms.stride;
+        wload1(wa, 0);
+        wload2();
+    }
 
     // LDS: obs [32][cells] | legal [32][cells] | hA [64][32] floats | hB [64][32] floats | reduction 3 x [32]
     const int img = (32 * cells + 15) & ~15;
