@@ -24,6 +24,13 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+try:    # one C call instead of building a torch.cuda.Stream object per launch (~1.5 us of a ~7 us host-side step)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 class HexVecEnv:
     def __init__(self, board_size=11, num_envs=1024, device=None, seed=0, encoding="B",
                  two_sided=False, agent_player_num=None, auto_reset=True, first_player=0,
@@ -43,6 +50,7 @@ class HexVecEnv:
             raise RuntimeError("HexVecEnv runs on the GPU only (device must be cuda:N)")
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
+        self._dev_index = idx
         flags = 0
         if encoding == "B":
             flags |= _lib.F_ENC_B
@@ -88,6 +96,10 @@ class HexVecEnv:
         self.done = torch.empty(E, dtype=torch.uint8, device=dev)
         self.winner = torch.empty(E, dtype=torch.int8, device=dev)
         self.pending = torch.zeros(E, dtype=torch.uint8, device=dev)
+        # the env's own output buffers never move: their pointers are wrapped once (a host-stepped call is ~7 us of
+        # Python around a ~5 us kernel at small env counts)
+        self._po, self._pl, self._pr = _p(self.obs), _p(self.legal), _p(self.reward)
+        self._pd, self._pw, self._pp = _p(self.done), _p(self.winner), _p(self.pending)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -102,7 +114,9 @@ class HexVecEnv:
             pass
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        """the caller's current stream on this device, as the ABI wants it (queried per call: a graph capture or a
+        `with torch.cuda.stream(...)` block changes it)"""
+        return C.c_void_p(_raw_stream(self._dev_index))
 
     def _i32(self, a, shape):
         if a is None:
@@ -145,9 +159,10 @@ class HexVecEnv:
         a = self._i32(actions, (self.num_envs,))
         o = self._i32(opp_actions, (self.num_envs,))
         self._tobs(terminal_obs)
-        _lib.check(self._L.hexvec_step(self._h, _p(a), _p(o), _p(self.obs), _p(self.legal),
-                                       _p(self.reward), _p(self.done), _p(self.winner),
-                                       _p(terminal_obs), self._stream()))
+        rc = self._L.hexvec_step(self._h, _p(a), _p(o), self._po, self._pl, self._pr, self._pd, self._pw,
+                                 _p(terminal_obs), C.c_void_p(_raw_stream(self._dev_index)))
+        if rc:
+            _lib.check(rc)
         return self.obs, self.reward, self.done, self.legal, self.winner
 
     def step_agent(self, actions=None, terminal_obs=None):
@@ -159,9 +174,10 @@ class HexVecEnv:
         after the last call."""
         a = self._i32(actions, (self.num_envs,))
         self._tobs(terminal_obs)
-        _lib.check(self._L.hexvec_step_agent(self._h, _p(a), _p(self.obs), _p(self.legal),
-                                             _p(self.reward), _p(self.done), _p(self.winner),
-                                             _p(terminal_obs), _p(self.pending), self._stream()))
+        rc = self._L.hexvec_step_agent(self._h, _p(a), self._po, self._pl, self._pr, self._pd, self._pw,
+                                       _p(terminal_obs), self._pp, C.c_void_p(_raw_stream(self._dev_index)))
+        if rc:
+            _lib.check(rc)
         return self.obs, self.legal, self.pending
 
     def step_opponent(self, opp_actions=None, terminal_obs=None):
@@ -169,9 +185,10 @@ class HexVecEnv:
         -> (obs, reward, done, legal, winner, pending)."""
         o = self._i32(opp_actions, (self.num_envs,))
         self._tobs(terminal_obs)
-        _lib.check(self._L.hexvec_step_opponent(self._h, _p(o), _p(self.obs), _p(self.legal),
-                                                _p(self.reward), _p(self.done), _p(self.winner),
-                                                _p(terminal_obs), _p(self.pending), self._stream()))
+        rc = self._L.hexvec_step_opponent(self._h, _p(o), self._po, self._pl, self._pr, self._pd, self._pw,
+                                          _p(terminal_obs), self._pp, C.c_void_p(_raw_stream(self._dev_index)))
+        if rc:
+            _lib.check(rc)
         return self.obs, self.reward, self.done, self.legal, self.winner, self.pending
 
     def apply_moves(self, actions):
