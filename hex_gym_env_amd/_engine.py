@@ -57,6 +57,12 @@ class _BoardEngine:
         self._tk[0] = 0
         self._expect = 0
         _lib.check(self._L.hexvec_set_ticket(self._h, self._p_tk))
+        # scalar I/O of a ply through ctypes views of the same pinned words (a numpy element access costs ~3x as much)
+        self._c_act = C.c_int32.from_address(self._t_act.data_ptr())
+        self._c_ret = C.c_int8.from_address(self._t_ret.data_ptr())
+        self._c_done = C.c_uint8.from_address(self._t_done.data_ptr())
+        self._c_rb = C.c_int8.from_address(self._t_rb.data_ptr())
+        self._c_tk = C.c_uint32.from_address(self._t_tk.data_ptr())
         self._apply = self._L.hexvec_apply_moves
         self._apply_args = (self._h, self._p_act, 1, self._p_ret, self._p_done, self._p_rb, self._p_lg, self._p_ob,
                             self._st)
@@ -89,22 +95,22 @@ class _BoardEngine:
 
     def ply(self, action):
         """one literal ply; returns (ret code, done flag, reward[0])"""
-        self._act[0, 0] = action
+        self._c_act.value = int(action)
         rc = self._apply(*self._apply_args)
         if rc:
             _lib.check(rc)
         # wait for the kernel's ticket (one board = +1 per launch) instead of a stream wait
         want = self._expect = (self._expect + 1) & 0xFFFFFFFF
-        tk = self._tk
-        for _ in range(200000):             # ~10 ms of polling, then the blocking wait decides
-            if tk[0] == want:
+        tk = self._c_tk
+        for _ in range(400000):             # ~10 ms of polling, then the blocking wait decides
+            if tk.value == want:
                 break
         else:
             self._wait()
-            if int(tk[0]) != want:
+            if tk.value != want:
                 raise RuntimeError("libhexvec: the ply kernel did not signal its completion ticket")
         self._board = self._legal = self._labels = self._cur = None
-        return int(self._ret[0, 0]), bool(self._done[0, 0]), int(self._rb[0, 0])
+        return self._c_ret.value, self._c_done.value != 0, self._c_rb.value
 
     @property
     def board(self):
