@@ -15,7 +15,7 @@ struct hexvec {
     uint64_t seed;
     hv::u32 *planes;
     hv::u32 *hot;
-    int *stats;
+    long long *stats;
     bool fast_mode;      // throughput kernels + fast state (auto-reset handles)
     bool qpb;            // fast_mode: bitboard kernels (hexvec_qpb.h); else the LDS union-find ones (hexvec_lpb.h)
     unsigned char *fast;
@@ -182,7 +182,7 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
         h->qpb = strcmp(ev, "lpb") == 0 ? false : (strcmp(ev, "qpb") == 0 ? true : h->qpb);
     if (h->fast_mode && h->qpb) {
         const int bpw = 64 / hv::qpb_lanes(board_size);
-        const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 16;
+        const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 32; // + [E][4] 64-bit episode sums
         h->fast_bytes = bytes;
         ok = hipMalloc(&h->fast, bytes) == hipSuccess;
     } else if (h->fast_mode) {
@@ -193,7 +193,7 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     } else {
         ok = hipMalloc(&h->planes, E * hv::PLANE_WORDS * 4) == hipSuccess &&
              hipMalloc(&h->hot, E * hv::HOT_WORDS * 4) == hipSuccess &&
-             hipMalloc(&h->stats, E * hv::STAT_WORDS * 4) == hipSuccess;
+             hipMalloc(&h->stats, E * hv::STAT_WORDS * 8) == hipSuccess;
     }
     if (!ok) {
         hexvec_destroy(h);
@@ -468,7 +468,7 @@ extern "C" int hexvec_agent_colours(hexvec_t *h, uint8_t *out, void *stream)
 static size_t state_bytes(const hexvec *h)
 {
     const size_t E = (size_t)h->E;
-    return h->fast_mode ? h->fast_bytes : E * (hv::PLANE_WORDS + hv::HOT_WORDS + hv::STAT_WORDS) * 4;
+    return h->fast_mode ? h->fast_bytes : E * (hv::PLANE_WORDS + hv::HOT_WORDS + 2 * hv::STAT_WORDS) * 4;
 }
 extern "C" size_t hexvec_state_bytes(const hexvec_t *h) { return h ? state_bytes(h) : 0; }
 
@@ -487,7 +487,7 @@ extern "C" int hexvec_export_state(hexvec_t *h, void *dst, void *stream)
         d += E * hv::PLANE_WORDS * 4;
         HV_HIP(hipMemcpyAsync(d, h->hot, E * hv::HOT_WORDS * 4, hipMemcpyDeviceToDevice, st));
         d += E * hv::HOT_WORDS * 4;
-        HV_HIP(hipMemcpyAsync(d, h->stats, E * hv::STAT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        HV_HIP(hipMemcpyAsync(d, h->stats, E * hv::STAT_WORDS * 8, hipMemcpyDeviceToDevice, st));
     }
     return HEXVEC_OK;
 }
@@ -507,7 +507,7 @@ extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
         d += E * hv::PLANE_WORDS * 4;
         HV_HIP(hipMemcpyAsync(h->hot, d, E * hv::HOT_WORDS * 4, hipMemcpyDeviceToDevice, st));
         d += E * hv::HOT_WORDS * 4;
-        HV_HIP(hipMemcpyAsync(h->stats, d, E * hv::STAT_WORDS * 4, hipMemcpyDeviceToDevice, st));
+        HV_HIP(hipMemcpyAsync(h->stats, d, E * hv::STAT_WORDS * 8, hipMemcpyDeviceToDevice, st));
     }
     return HEXVEC_OK;
 }

@@ -15,7 +15,7 @@ typedef unsigned long long u64;
 constexpr int WPB = 4;        // wavefronts (= boards) per workgroup
 constexpr int PLANE_WORDS = 3 * 64; // per env: L0, L1, F|FT<<4   (768 B)
 constexpr int HOT_WORDS = 8;  // per env: counters touched every step (32 B)
-constexpr int STAT_WORDS = 4; // per env: episode sums, touched at episode end
+constexpr int STAT_WORDS = 4; // per env: episode sums (64-bit each), touched at episode end
 
 enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6 };
 
@@ -23,7 +23,7 @@ struct KArgs {
     unsigned char *fast; // lane-per-board state (fast handles)
     u32 *planes;
     u32 *hot;
-    int *stats;
+    long long *stats; // literal-engine handles: [E][STAT_WORDS] episode sums since create (64-bit: sum_len passes 2^31 within hours)
     int E;
     u32 env_offset, seed_lo, seed_hi, flags;
     int T;
@@ -93,7 +93,7 @@ void set_error(const char *what, const char *detail);
 hipError_t wpb_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
 hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int enc, signed char *board,
                          unsigned char *labels, unsigned char *cur, hipStream_t st);
-hipError_t wpb_stats(const int *stats, int E, double *out4, hipStream_t st);
+hipError_t wpb_stats(const long long *stats, int E, double *out4, hipStream_t st);
 hipError_t wpb_agents(const u32 *hot, int E, unsigned char *out, hipStream_t st);
 
 hipError_t lpb64_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);

@@ -145,8 +145,29 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         u32 ctr, key;
         u32 kc; // key + ctr * 0x9E3779B9, kept in step with ctr (no multiply per draw)
         int ep_ret, ep_len;
-        int sr, sl, se, sw;
+        // episode sums since create, LOW words (sr biased by 2^31 so that a return sum around zero does not
+        // carry).  The high words live behind the block's register rows in HBM and are touched only by the
+        // lane whose low word carries (sum_len passes 2^31 after ~2 h of rollouts): add_sums().
+        u32 sr, sl, se, sw;
     };
+    static constexpr u32 SR_BIAS = 0x80000000u;
+    // finished episode -> the 64-bit sums; hi = the block's [4][64] high words
+    static __device__ __forceinline__ void add_sums(LS &s, int won, u32 *hi, int lane)
+    {
+        const u32 o_sr = s.sr, o_sl = s.sl;
+        s.sr += (u32)s.ep_ret;
+        s.sl += (u32)s.ep_len;
+        s.se += 1u;
+        s.sw += (u32)won;
+        const int d_sr = (int)(s.sr < o_sr) - (int)(s.ep_ret < 0); // carry out of the low word - sign extension
+        const bool c_sl = s.sl < o_sl, c_se = s.se == 0u, c_sw = won && s.sw == 0u;
+        if (d_sr != 0 || c_sl || c_se || c_sw) { // once per 2^31 steps of a board
+            hi[0 * 64 + lane] += (u32)d_sr;
+            hi[1 * 64 + lane] += c_sl ? 1u : 0u;
+            hi[2 * 64 + lane] += c_se ? 1u : 0u;
+            hi[3 * 64 + lane] += c_sw ? 1u : 0u;
+        }
+    }
 
     static __device__ __forceinline__ int transpose(int a)
     {
@@ -514,11 +535,13 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
     }
 };
 
-// fast state in HBM, per block of 64 boards: [LDS image][REGW x 64 words]
+// fast state in HBM, per block of 64 boards: [LDS image][REGW x 64 words][4 x 64 high words of the episode sums]
+// (the last four rows are not part of what a launch loads and stores: Lpb::add_sums)
 template <int N, int ENC, int BPW, int VIEWS> struct FastState {
     using L = Lpb<N, ENC, BPW, VIEWS>;
     static constexpr int REGW = Regs<N>::REGW;
-    static constexpr size_t BLOCK_BYTES = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
+    static constexpr size_t HI_OFF = (size_t)L::LDS_BYTES + (size_t)REGW * 64 * 4;
+    static constexpr size_t BLOCK_BYTES = HI_OFF + (size_t)4 * 64 * 4;
 };
 
 // HELPER = 1: 128-thread workgroups.  Wave 0 plays; wave 1 only copies observations: at every emission
@@ -547,6 +570,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     const int nlive = min(BPW, a.E - e0);
     unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
     u32 *rblk = reinterpret_cast<u32 *>(sblk + L::LDS_BYTES);
+    u32 *hblk = reinterpret_cast<u32 *>(sblk + FastState<N, ENC, BPW, VIEWS>::HI_OFF);
     const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
@@ -611,7 +635,10 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.winner = -1;
         s.agent = !B ? 0 : (a.flags & HEXVEC_F_AGENT_RANDOM) ? (int)(mix32(s.key ^ 0xA5A5A5A5U) & 1u)
                   : (a.flags & HEXVEC_F_AGENT_WHITE) ? 1 : 0;
-        s.sr = s.sl = s.se = s.sw = 0;
+        s.sr = L::SR_BIAS;
+        s.sl = s.se = s.sw = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hblk[k * 64 + lane] = 0u;
         s.pend = 0;
         L::fresh_regs(s, first);
     } else {
@@ -646,10 +673,10 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.n_empty = (int)(fl >> 8) & 0xff;
         s.pend = (int)(fl >> 16) & 3;
         s.prewon = (int)(fl >> 18) & 3;
-        s.sr = (int)r[4 * 64 + lane];
-        s.sl = (int)r[5 * 64 + lane];
-        s.se = (int)r[6 * 64 + lane];
-        s.sw = (int)r[7 * 64 + lane];
+        s.sr = r[4 * 64 + lane];
+        s.sl = r[5 * 64 + lane];
+        s.se = r[6 * 64 + lane];
+        s.sw = r[7 * 64 + lane];
     }
 
     HV_PHASE(blk, 1);
@@ -726,10 +753,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         if (tobs_row) L::copy_rows(lds, dmask, B ? __ballot(s.cur != 0) : 0ull, agent1, tobs_row, lane);
         L::clear_boards(lds, dmask, lane);
         if (dn) {
-            s.sr += s.ep_ret;
-            s.sl += s.ep_len;
-            s.se += 1;
-            s.sw += won;
+            L::add_sums(s, won, hblk, lane);
             L::fresh_regs(s, first);
         }
     };
@@ -952,10 +976,10 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     r[2 * 64 + lane] = (u32)s.ep_len;
     r[3 * 64 + lane] = (u32)s.cur | ((u32)s.done << 2) | ((u32)s.agent << 3) | ((u32)(s.winner + 1) << 4) |
                        ((u32)(s.n_empty & 0xff) << 8) | ((u32)s.pend << 16) | ((u32)s.prewon << 18);
-    r[4 * 64 + lane] = (u32)s.sr;
-    r[5 * 64 + lane] = (u32)s.sl;
-    r[6 * 64 + lane] = (u32)s.se;
-    r[7 * 64 + lane] = (u32)s.sw;
+    r[4 * 64 + lane] = s.sr;
+    r[5 * 64 + lane] = s.sl;
+    r[6 * 64 + lane] = s.se;
+    r[7 * 64 + lane] = s.sw;
     HV_PHASE(blk, 3);
 }
 
@@ -997,7 +1021,11 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
         const unsigned char *sblk = fast + (size_t)(i / BPW) * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
         const u32 *regs = reinterpret_cast<const u32 *>(sblk + L::LDS_BYTES) + 2 * Geo<N, BPW>::JW * 64;
-        for (int k = 0; k < 4; ++k) acc[k] += (double)(int)regs[(4 + k) * 64 + (i % BPW)];
+        const u32 *hi = reinterpret_cast<const u32 *>(sblk + FastState<N, ENC, BPW, VIEWS>::HI_OFF);
+        for (int k = 0; k < 4; ++k) { // 64-bit sums (exact in a double below 2^53); the return sum is kept biased
+            const long long v = (long long)(((u64)hi[k * 64 + (i % BPW)] << 32) | (u64)regs[(4 + k) * 64 + (i % BPW)]);
+            acc[k] += (double)(k == 0 ? v - (long long)L::SR_BIAS : v);
+        }
         if (agents) agents[i] = (unsigned char)((regs[3 * 64 + (i % BPW)] >> 3) & 1u);
     }
     if (!out4) return;

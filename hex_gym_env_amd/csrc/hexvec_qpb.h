@@ -352,7 +352,8 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     const int env = e0 + brow;
     const bool live = env < a.E;
     u32 *rblk = reinterpret_cast<u32 *>(a.fast + (size_t)blk * G::BLOCK_BYTES);
-    int *stats = reinterpret_cast<int *>(a.fast + (size_t)nb * G::BLOCK_BYTES) + (size_t)env * 4; // [E][4]
+    // [E][4] 64-bit episode sums since create (sum_len alone passes 2^31 after hours of rollouts), behind the blocks
+    longlong2 *stats = reinterpret_cast<longlong2 *>(a.fast + (size_t)nb * G::BLOCK_BYTES) + (size_t)env * 2;
     const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
@@ -371,7 +372,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                   : (a.flags & HEXVEC_F_AGENT_WHITE) ? 1 : 0;
         s.pend = 0;
         QQ::fresh_regs(s, first);
-        if (c.l == 0) *reinterpret_cast<int4 *>(stats) = make_int4(0, 0, 0, 0);
+        if (c.l == 0) stats[0] = stats[1] = make_longlong2(0, 0);
     } else {
         s.K0 = rblk[0 * 64 + lane];
         s.K1 = rblk[1 * 64 + lane];
@@ -657,12 +658,13 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     for (int k = 0; k < G::NSC; ++k)
         if (c.l == k % L) rblk[(8 + k / L) * 64 + lane] = k == 0 ? s.ctr : (k == 1 ? fl : ep);
     if (c.l == 0 && s.se != 0) { // episode sums: touched only when an episode ended in this launch
-        int4 v = *reinterpret_cast<int4 *>(stats);
-        v.x += s.sr;
-        v.y += s.sl;
-        v.z += s.se;
-        v.w += s.sw;
-        *reinterpret_cast<int4 *>(stats) = v;
+        longlong2 v0 = stats[0], v1 = stats[1];
+        v0.x += s.sr;
+        v0.y += s.sl;
+        v1.x += s.se;
+        v1.y += s.sw;
+        stats[0] = v0;
+        stats[1] = v1;
     }
 }
 
@@ -701,14 +703,14 @@ __global__ __launch_bounds__(256) void k_qpb_stats(const unsigned char *fast, in
     constexpr int L = G::L, BPW = G::BPW;
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
-    const int *stats = reinterpret_cast<const int *>(fast + (size_t)nblocks * G::BLOCK_BYTES);
+    const longlong2 *stats = reinterpret_cast<const longlong2 *>(fast + (size_t)nblocks * G::BLOCK_BYTES);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) {
         if (out4) {
-            const int4 v = *reinterpret_cast<const int4 *>(stats + (size_t)i * 4);
-            acc[0] += v.x;
-            acc[1] += v.y;
-            acc[2] += v.z;
-            acc[3] += v.w;
+            const longlong2 v0 = stats[(size_t)i * 2], v1 = stats[(size_t)i * 2 + 1];
+            acc[0] += (double)v0.x; // exact below 2^53
+            acc[1] += (double)v0.y;
+            acc[2] += (double)v1.x;
+            acc[3] += (double)v1.y;
         }
         if (agents) {
             const u32 *rb = reinterpret_cast<const u32 *>(fast + (size_t)(i / BPW) * G::BLOCK_BYTES);

@@ -507,9 +507,9 @@ __global__ __launch_bounds__(64 * WPB) void k_hex(KArgs a)
                   : lane == 3 ? fl : lane == 4 ? cn : 0u;
     if (lane < HOT_WORDS) hot[lane] = hwv;
     if (se && lane < STAT_WORDS) {
-        int *st = a.stats + (size_t)env * STAT_WORDS;
+        long long *st = a.stats + (size_t)env * STAT_WORDS;
         const int add = lane == 0 ? sr : lane == 1 ? sl : lane == 2 ? se : sw;
-        st[lane] += add;
+        st[lane] += (long long)add;
     }
     // completion ticket (hexvec_set_ticket): every output of this board is out -- also those in host-pinned
     // memory across the bus -- before its wavefront adds 1; the host spins on the word instead of a stream wait
@@ -550,7 +550,7 @@ __global__ void k_get_state(const u32 *planes, const u32 *hot, int E, int N, int
     }
 }
 
-__global__ void k_stats(const int *stats, int E, double *out4)
+__global__ void k_stats(const long long *stats, int E, double *out4)
 {
     __shared__ double sh[4][256];
     double acc[4] = {0, 0, 0, 0};
@@ -616,7 +616,7 @@ hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int en
                        N, enc, board, labels, cur);
     return hipGetLastError();
 }
-hipError_t wpb_stats(const int *stats, int E, double *out4, hipStream_t st)
+hipError_t wpb_stats(const long long *stats, int E, double *out4, hipStream_t st)
 {
     // out4 was zeroed on the same stream (hexvec_episode_stats)
     const int grid = (E + 255) / 256 < 1024 ? (E + 255) / 256 : 1024;

@@ -58,17 +58,25 @@ def allreduce_gradients(params, average=True):
     ~41 k parameters = 164 KB in fp32 at 11x11) is far below one RCCL bucket, so ALL gradients travel as
     ONE flattened all-reduce (xGMI is point-to-point: one latency-bound ring pass instead of one per
     tensor), then are copied back in place.  A no-op without a process group.  Returns the bytes reduced."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    params = list(params)
+    if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    # EVERY parameter takes part, in the caller's order, zeros where this rank has no gradient (a head that a
+    # minibatch did not use): the flattened buffer has the same length and layout on every rank whatever each
+    # rank's minibatch touched -- a per-rank "grad is not None" filter would reduce misaligned buffers (or hang).
+    ref = next((p.grad for p in params if p.grad is not None), params[0])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(ref.dtype)
+                      for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        if p.grad is None:      # some other rank may have had one: adopt the reduced value
+            p.grad = flat[off:off + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
         off += n
     return flat.numel() * flat.element_size()
 

@@ -25,8 +25,8 @@ import torch
 from .opponent_buffer import OpponentBuffer
 from .vec_env import HexVecEnv
 
-__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "PredictAdapter", "as_policy", "VecSelfPlayEnv",
-           "sample_boards"]
+__all__ = ["RandomLegalPolicy", "MlpActorPolicy", "MlpCritic", "ppo_minibatch_step", "PredictAdapter", "as_policy",
+           "VecSelfPlayEnv", "sample_boards"]
 
 
 def sample_boards(board_size, count, generator, device):
@@ -290,6 +290,11 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         z = self.action_net(self.policy_net(x)).to(obs.device)
         return z.masked_fill(legal == 0, float("-inf"))
 
+    @torch.no_grad()
+    def masked_logits(self, obs_float, legal_bool):
+        """as logits(), for inputs that are already float [B, C] / bool [B, C] on the parameters' device"""
+        return self.action_net(self.policy_net(obs_float)).masked_fill(~legal_bool, float("-inf"))
+
     # -- the fused path: weights packed for hexvec_mlp_actions (include/hexvec.h) --
     def weights_version(self):
         """changes whenever a parameter is written in place (optimizer step, load_state_dict) or replaced (.to())"""
@@ -371,6 +376,52 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         if owner is not None:           # a view of an SB3 model: OpponentPolicy.save_model (SelfplayWrapper.py:37-38)
             return owner.save(path)
         torch.save(self.state_dict(), path)
+
+
+class MlpCritic(torch.nn.Module):
+    """The critic of SB3's default MlpPolicy: flatten -> Linear-Tanh-Linear-Tanh (mlp_extractor.value_net) ->
+    Linear(., 1) (value_net).  Training-side only: no kernel of libhexvec touches it."""
+
+    def __init__(self, n_cells, hidden=(64, 64)):
+        super().__init__()
+        dims = [n_cells] + list(hidden)
+        layers = []
+        for a, b in zip(dims, dims[1:]):
+            layers += [torch.nn.Linear(a, b), torch.nn.Tanh()]
+        self.value_net = torch.nn.Sequential(*layers, torch.nn.Linear(dims[-1], 1))
+
+    def forward(self, obs):
+        return self.value_net(obs.reshape(obs.shape[0], -1).float()).squeeze(-1)
+
+
+def ppo_minibatch_step(actor, critic, optimizer, obs, legal, actions, old_logp, advantages, returns,
+                       clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, allreduce=False):
+    """One optimizer step of MaskablePPO's update on one minibatch (the loss of sb3_contrib's train(): clipped
+    surrogate on the masked categorical, value MSE, entropy bonus, gradient clipping) in plain fp32 torch.  The
+    reference's scripts run this inside sb3_contrib (scripts/experiments/*.py:38-47); here it exists so that the
+    update leg of a training iteration can be timed next to the collection step and so that
+    dist.allreduce_gradients has a caller (allreduce=True: data-parallel step, one flattened all-reduce).
+    obs float [B, C], legal bool [B, C], actions int64 [B], old_logp / advantages / returns float [B].
+    Returns the loss (a device scalar; nothing synchronises)."""
+    logits = actor.action_net(actor.policy_net(obs)).masked_fill(~legal, float("-inf"))
+    logp_all = torch.log_softmax(logits, -1)
+    logp = logp_all.gather(1, actions[:, None]).squeeze(1)
+    ratio = torch.exp(logp - old_logp)
+    adv = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1.0 - clip, 1.0 + clip)).mean()
+    vf = torch.nn.functional.mse_loss(critic(obs), returns)
+    p_all = logp_all.exp()
+    ent = -(p_all * logp_all.masked_fill(~legal, 0.0)).sum(-1).mean()
+    loss = pg + vf_coef * vf - ent_coef * ent
+    optimizer.zero_grad(set_to_none=False)
+    loss.backward()
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    if allreduce:
+        from . import dist as hxdist
+        hxdist.allreduce_gradients(params)
+    torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+    optimizer.step()
+    return loss.detach()
 
 
 class PredictAdapter:

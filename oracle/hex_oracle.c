@@ -692,6 +692,40 @@ void hexo_vec_rollout(hexo_vec *v, int T, int8_t *obs, uint8_t *legal, int32_t *
     parallel_for(v, ro_range, &a);
 }
 
+/* ---- W1 rollout: T whole env steps with the RNG agent, every step recorded (the agent's action in the
+ * view it was shown; obs/mask AFTER the step, as hexo_vec_step returns them) ---- */
+static void ro1_range(hexo_vec *v, int lo, int hi, void *p)
+{
+    ro_args *a = (ro_args *)p;
+    const int C = v->n * v->n;
+    const size_t E = (size_t)v->E;
+    for (int t = 0; t < a->T; ++t)
+        for (int i = lo; i < hi; ++i) {
+            venv *e = &v->envs[i];
+            size_t o = (size_t)t * E + (size_t)i;
+            step_args s = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 1};
+            float rew;
+            uint8_t dn;
+            int32_t act32 = rng_action_stored(v, e); /* the draw step_one would make itself */
+            s.actions = &act32 - i;                  /* step_one indexes by i */
+            s.reward = &rew - i;
+            s.done = &dn - i;
+            s.obs = a->obs ? a->obs + (o - (size_t)i) * C : NULL;
+            s.legal = a->legal ? a->legal + (o - (size_t)i) * C : NULL;
+            step_one(v, e, i, &s);
+            if (a->actions) a->actions[o] = act32;
+            if (a->reward) a->reward[o] = rew;
+            if (a->done) a->done[o] = dn;
+        }
+}
+
+void hexo_vec_rollout_selfplay(hexo_vec *v, int T, int8_t *obs, uint8_t *legal, int32_t *actions,
+                               float *reward, uint8_t *done)
+{
+    ro_args a = {T, obs, legal, actions, reward, done};
+    parallel_for(v, ro1_range, &a);
+}
+
 void hexo_vec_get_state(hexo_vec *v, int8_t *board, uint8_t *labels, uint8_t *cur_player)
 {
     const int C = v->n * v->n, P = (v->n + 2) * (v->n + 2);

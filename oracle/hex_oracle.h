@@ -124,6 +124,10 @@ void hexo_vec_apply_moves(hexo_vec *v, const int32_t *actions, int T, int8_t *re
 /* W2: T plies, both sides RNG, every ply recorded (obs/mask BEFORE the ply) */
 void hexo_vec_rollout(hexo_vec *v, int T, int8_t *obs, uint8_t *legal, int32_t *actions,
                       float *reward, uint8_t *done);
+/* W1: T whole env steps (hexo_vec_step with the RNG agent and opponent), every step recorded: the agent's
+ * action, reward, done, obs/mask AFTER the step */
+void hexo_vec_rollout_selfplay(hexo_vec *v, int T, int8_t *obs, uint8_t *legal, int32_t *actions,
+                               float *reward, uint8_t *done);
 void hexo_vec_get_state(hexo_vec *v, int8_t *board, uint8_t *labels, uint8_t *cur_player);
 void hexo_vec_episode_stats(hexo_vec *v, double *out4);
 void hexo_vec_agent_colours(hexo_vec *v, uint8_t *out);

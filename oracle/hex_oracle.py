@@ -114,6 +114,8 @@ def lib():
     L.hexo_vec_apply_moves.restype = None
     L.hexo_vec_rollout.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.hexo_vec_rollout.restype = None
+    L.hexo_vec_rollout_selfplay.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.hexo_vec_rollout_selfplay.restype = None
     L.hexo_vec_get_state.argtypes = [vp, vp, vp, vp]
     L.hexo_vec_get_state.restype = None
     L.hexo_vec_episode_stats.argtypes = [vp, vp]
@@ -205,6 +207,17 @@ class OracleVec:
         rew = np.empty((T, E), np.float32)
         done = np.empty((T, E), np.uint8)
         self.L.hexo_vec_rollout(self.h, T, _ptr(obs), _ptr(legal), _ptr(act), _ptr(rew), _ptr(done))
+        return obs, legal, act, rew, done
+
+    def rollout_selfplay(self, T):
+        """W1: T whole env steps, RNG agent and opponent -> obs, legal (after each step), the agent's action, reward, done"""
+        E, Cc = self.E, self.C
+        obs = np.empty((T, E, Cc), np.int8)
+        legal = np.empty((T, E, Cc), np.uint8)
+        act = np.empty((T, E), np.int32)
+        rew = np.empty((T, E), np.float32)
+        done = np.empty((T, E), np.uint8)
+        self.L.hexo_vec_rollout_selfplay(self.h, T, _ptr(obs), _ptr(legal), _ptr(act), _ptr(rew), _ptr(done))
         return obs, legal, act, rew, done
 
     def get_state(self):

@@ -118,3 +118,92 @@ def test_two_rank_gradient_allreduce_matches_the_full_batch():
         assert nbytes == 4 * nparams
         for g, p in zip(grads, pol.parameters()):
             assert np.allclose(g, p.grad.numpy(), atol=1e-6)
+
+
+def _ragged_grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hex_gym_env_amd.dist import allreduce_gradients
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 3), torch.nn.Linear(4, 2)     # rank 1's minibatch never reaches head b
+    x = torch.randn(8, 4, generator=torch.Generator().manual_seed(7 + rank))
+    loss = a(x).sum() + (b(x).sum() if rank == 0 else 0.0)
+    loss.backward()
+    params = list(a.parameters()) + list(b.parameters())
+    assert (b.weight.grad is None) == (rank == 1)
+    nbytes = allreduce_gradients(params)
+    q.put((rank, nbytes, [p.grad.clone().numpy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_with_a_parameter_unused_on_one_rank():
+    """every parameter takes part on every rank (zeros where a rank has no gradient), so the flattened buffers
+    line up even when one rank's minibatch did not touch a head; both ranks end with the same averaged gradients"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(4, 3), torch.nn.Linear(4, 2)
+    xs = [torch.randn(8, 4, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+    ((a(xs[0]).sum() + b(xs[0]).sum() + a(xs[1]).sum()) / world).backward()
+    want = [p.grad.numpy() for p in list(a.parameters()) + list(b.parameters())]
+    for rank, nbytes, grads in res:
+        assert nbytes == 4 * sum(w.size for w in want)
+        for g, w in zip(grads, want):
+            assert np.allclose(g, w, atol=1e-6), rank
+
+
+def _ppo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy, MlpCritic, ppo_minibatch_step
+    torch.manual_seed(0)
+    actor, critic = MlpActorPolicy(25), MlpCritic(25)
+    opt = torch.optim.SGD(list(actor.parameters()) + list(critic.parameters()), lr=0.1)
+    batch = _ppo_batch(100 + rank)
+    ppo_minibatch_step(actor, critic, opt, *batch, max_grad_norm=1e9, allreduce=True)
+    q.put((rank, [p.detach().clone().numpy() for p in list(actor.parameters()) + list(critic.parameters())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ppo_batch(seed, B=96, C=25):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randint(-1, 2, (B, C), generator=g).float()
+    legal = obs == 0
+    legal[:, 0] = True
+    act = torch.multinomial(legal.float(), 1, generator=g).squeeze(1)
+    return obs, legal, act, -torch.rand(B, generator=g) - 1.0, torch.randn(B, generator=g), torch.randn(B, generator=g)
+
+
+def test_two_rank_data_parallel_ppo_step_keeps_the_replicas_identical():
+    """ppo_minibatch_step(allreduce=True): each rank back-propagates ITS minibatch, the gradients are averaged in one
+    flattened all-reduce, and both replicas take the same optimizer step (the weights stay bit-equal)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ppo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0), (_, w1) = res
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy
+    torch.manual_seed(0)
+    init = [p.detach().numpy() for p in MlpActorPolicy(25).parameters()]
+    assert all(np.array_equal(a, b) for a, b in zip(w0, w1))
+    assert any(not np.array_equal(a, b) for a, b in zip(w0, init))     # a step was taken

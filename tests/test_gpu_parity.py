@@ -397,6 +397,37 @@ def test_rollout_selfplay_vs_oracle(hx, n, enc, exact):
     _same_state(g, o)
 
 
+# the kernel bench.py times, at the geometry it is timed at (many workgroups, XCD block remap, a ragged tail block
+# beside full ones, the helper wavefront's scalar path, in-kernel resets + openings, the LDS-DMA state reload across
+# launches): SelfplayWrapper.py:69-89, :174-199 through k_lpb<rollout1>, every recorded row against the oracle
+@pytest.mark.parametrize("n,E,enc,first,plan", [
+    (11, 4096, "B", 0, [20] * 10 + [200]),          # 64 workgroups = 8 per XCD; the driver's 20-step launches, then 200
+    (11, 4096 + 37, "B", 0, [20] * 10 + [200]),     # + a tail block (helper off) beside 64 full ones, odd block count
+    (13, 1024, "B", 0, [20] * 10 + [200, 100]),     # one image per board at the LDS limit
+    (5, 64 * 9 + 17, "B", 0, [7, 20, 33, 20, 20, 50]),
+    (7, 64 * 16, "B", 0, [20] * 5 + [100]),
+    (5, 64 * 9 + 17, "A", 1, [7, 20, 33, 20, 20, 50]),  # hex-v0, the opponent opens every episode
+    (11, 64 * 8, "A", 0, [20] * 5 + [150]),
+], ids=lambda v: None if isinstance(v, list) else str(v))
+def test_rollout1_at_bench_geometry_every_row_vs_oracle(hx, n, E, enc, first, plan):
+    g, o = _pair(hx, n, E, enc, agent=None, first=first, seed=20261005, exact="lpb")
+    o.set_threads(min(os.cpu_count() or 1, 64))
+    finished = np.zeros(E, np.int64)
+    for launch, T in enumerate(plan):
+        out = g.rollout_selfplay(T)
+        assert g.last_kernel() == "k_lpb<rollout1>"
+        oobs, olegal, oact, orew, odone = o.rollout_selfplay(T)
+        for k, ref in (("obs", oobs), ("legal", olegal), ("actions", oact), ("reward", orew), ("done", odone)):
+            got = _np(out[k])
+            if not np.array_equal(got, ref):
+                t, e = np.argwhere((got != ref).reshape(T, E, -1).any(-1))[0]
+                raise AssertionError(f"{k}: launch {launch} (T={T}) first differs at step {t}, env {e} (block {e // 64})")
+        finished += odone.sum(0)
+        assert np.array_equal(_np(g.episode_stats()), o.episode_stats()), launch
+    assert finished.min() >= 3, "every env must have run through several in-kernel resets"
+    _same_state(g, o)
+
+
 # ----------------------------------------------------------------------------
 # full-size properties (BASELINE.json configs[1]: 11x11, 65 536 envs)
 # ----------------------------------------------------------------------------
@@ -660,6 +691,54 @@ def test_config4_all_524288_envs_on_one_gpu_and_shard_identity(hx, lay, two):
             oo, ol, orw, od, ow = o.step()
             assert np.array_equal(_np(o2["obs"][t, :Eo]), oo), t
             assert np.array_equal(_np(o2["reward"][t, :Eo]), orw), t
+
+
+@FAMILIES
+def test_episode_sums_are_64_bit(hx, exact):
+    """hexvec_episode_stats reports sums since create: sum_len grows by ~3e5 per second and env in a rollout and passed
+    2^31 within two hours when the per-env sums were 32-bit.  A checkpoint whose per-env sums sit just below 2^31 /
+    2^32 is imported, more episodes are played, and the totals must come out exact (two handles, same seed: the
+    poked one must read the untouched one's totals + what was poked in).  Blob layout: include/hexvec.h
+    (hexvec_export_state) keeps it opaque; the offsets below are this library version's (csrc/hexvec_lpb.h
+    FastState, csrc/hexvec_qpb.h k_qpb `stats`, csrc/hexvec.hip export order)."""
+    n, E, T = 5, 200, 60
+    lpb = exact == "lpb"
+    kw = dict(encoding="B", seed=77, exact_labels=exact is True, rollout_layout=lpb)
+    a, b = hx.HexVecEnv(n, E, **kw), hx.HexVecEnv(n, E, **kw)
+    for _ in range(10):     # some history first
+        a.step()
+        b.step()
+    sd = b.state_dict()
+    blob = _np(sd["blob"]).copy()
+    add = np.zeros((E, 4), np.int64)       # what the poke adds to (sum_return, sum_len, n_episodes, n_wins) per env
+    if lpb:
+        nblk = (E + 63) // 64
+        blk = blob.reshape(nblk, -1)
+        rows = blk[:, -8 * 256:].view(np.uint32).reshape(nblk, 8, 64)   # lo sr sl se sw | hi sr sl se sw
+        for k, target in ((0, 0xFFFFFFFF), (1, 0xFFFFFFF0), (2, 0xFFFFFFFF), (3, 0x7FFFFFFB)):
+            old = rows[:, k, :].astype(np.int64).reshape(-1)[:E]
+            add[:, k] = target - old
+            rows[:, k, :] = target
+    else:
+        st = blob[-E * 32:].view(np.int64).reshape(E, 4)
+        for k, target in ((0, 2 ** 31 - 1), (1, 2 ** 32 - 16), (2, 2 ** 31 - 1), (3, 2 ** 31 - 5)):
+            add[:, k] = target - st[:, k]
+            st[:, k] = target
+    sd["blob"] = torch.from_numpy(blob).to(sd["blob"].device)
+    b.load_state_dict(sd)
+    if exact is True:
+        for _ in range(T):
+            a.step()
+            b.step()
+    else:
+        for _ in range(3):      # carried across launches too
+            a.rollout_selfplay(T // 3, out={})
+            b.rollout_selfplay(T // 3, out={})
+    sa, sb = _np(a.episode_stats()), _np(b.episode_stats())
+    assert sa[2] > 5 * E                                        # every env finished episodes after the import
+    want = sa + add.sum(0).astype(np.float64)
+    assert np.array_equal(sb, want), (sb - want)
+    assert sb[1] > E * 2.0 ** 32 and sb[2] > E * 2.0 ** 31       # past what 32-bit sums could hold
 
 
 def test_completion_ticket_counts_boards_behind_their_outputs(hx):

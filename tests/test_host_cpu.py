@@ -144,3 +144,75 @@ def test_committed_profile_matches_the_drivers_command():
     for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVES"):
         assert c[k] > 0, k
     assert d["kernel"].startswith("k_lpb")
+
+
+# ---- bench.py --gpus N: the ranks are started by bench.py itself when no launcher did ----
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_gpus_n_without_enough_gpus_refuses_instead_of_reporting_one():
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "n_gpus" not in p.stdout and "needs 2 visible GPUs" in p.stderr
+
+
+def test_bench_self_launch_builds_the_drivers_command_and_relays_rank0():
+    import json
+    import subprocess
+    import types
+    b = _bench()
+    cmd = b.launcher_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29517)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        line = json.dumps({"metric": "m", "value": 1.0, "n_gpus": seen["n"], "config": {"global_envs": 8 * 65536}})
+        return subprocess.CompletedProcess(cmd, seen["rc"], stdout="noise from a rank\n" + line + "\n")
+
+    args = types.SimpleNamespace(gpus=8, dry_ranks=False)
+    seen.update(n=8, rc=0)
+    assert b.self_launch(args, ["--gpus", "8", "--force-launcher"], run=fake_run, visible=8) == 0
+    assert "--force-launcher" not in seen["cmd"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen.update(n=1, rc=0)          # ranks that report another size: refused
+    assert b.self_launch(args, ["--gpus", "8"], run=fake_run, visible=8) != 0
+    seen.update(n=8, rc=1)          # a failing launch keeps its exit code
+    assert b.self_launch(args, ["--gpus", "8"], run=fake_run, visible=8) == 1
+    assert b.self_launch(args, ["--gpus", "8"], run=fake_run, visible=4) == 2      # fewer GPUs than asked for
+
+
+def test_bench_gpus_2_starts_two_real_ranks_and_prints_n_gpus_2():
+    """the whole self-launch path with real processes: `bench.py --gpus 2 --dry-ranks` (no launcher environment)
+    starts two ranks under torch.distributed.run as a child, the ranks run the bench's rank plumbing (process group,
+    barrier, max over ranks, the stats all_gather) over gloo, and rank 0's line comes back with n_gpus == 2"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks", "--envs", "65536"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_envs"] == 2 * 65536 and d["dry"] is True
+    assert d["max_over_ranks"] == 2.0 and d["stats_total"] == [2.0, 4.0, 6.0, 1.0]
+    # under a launcher whose world size differs from --gpus the ranks refuse
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-ranks"],
+                       capture_output=True, text=True, timeout=300, env=env2)
+    assert p.returncode != 0 and "n_gpus" not in p.stdout

@@ -200,3 +200,25 @@ def test_config1_thousand_games_5x5():
         assert sim.done and rets[g, last] in (0, 1)
         wins[int(rets[g, last])] += 1
     assert sum(wins) == 1000 and wins[0] > wins[1]          # the first mover wins more often
+
+
+@pytest.mark.parametrize("n,enc_flags", [(5, ho.F_ENC_B | ho.F_AGENT_RANDOM), (7, ho.F_ENC_B | ho.F_AGENT_WHITE),
+                                         (6, ho.F_FIRST_WHITE), (11, ho.F_ENC_B | ho.F_AGENT_RANDOM)])
+def test_vector_w1_rollout_is_the_stepped_contract(n, enc_flags):
+    """layer 2 only: hexo_vec_rollout_selfplay (what the GPU's rollout_selfplay is compared with) records exactly
+    what hexo_vec_step returns step by step -- same draws, plus the agent's action, which is always a legal cell of
+    the position the agent was shown; threads do not change the result"""
+    E, T = 96, 3 * n * n
+    a, b = ho.OracleVec(n, E, seed=5, flags=enc_flags, env_offset=17), ho.OracleVec(n, E, seed=5, flags=enc_flags, env_offset=17)
+    b.set_threads(4)
+    prev_legal = a.reset()[1]
+    b.reset()
+    obs, legal, act, rew, done = b.rollout_selfplay(T)
+    for t in range(T):
+        so, sl, sr, sd, sw = a.step()
+        assert np.array_equal(obs[t], so) and np.array_equal(legal[t], sl), t
+        assert np.array_equal(rew[t], sr) and np.array_equal(done[t], sd), t
+        assert prev_legal[np.arange(E), act[t]].all(), t
+        prev_legal = sl
+    assert np.array_equal(a.episode_stats(), b.episode_stats()) and a.episode_stats()[2] > E
+    assert np.array_equal(a.get_state()[0], b.get_state()[0])
