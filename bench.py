@@ -422,8 +422,8 @@ def main():
             from hex_gym_env_amd.vec_selfplay import ppo_minibatch_step, MlpCritic
             critic = MlpCritic(n3 * n3).to(dev)
             opt = torch.optim.Adam(list(agent.parameters()) + list(critic.parameters()), lr=3e-4)
-            obs3 = env3.env.obs.reshape(E3, -1).float().clone()
-            legal3 = env3.env.legal.bool().clone()
+            obs3 = env3.vec.obs.reshape(E3, -1).float().clone()
+            legal3 = env3.vec.legal.bool().clone()
             with torch.no_grad():
                 lg = agent.masked_logits(obs3, legal3)
                 act3 = torch.distributions.Categorical(logits=lg).sample()

@@ -70,7 +70,8 @@ struct StampBox {
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime(); \
     g_box.acc[0] = g_box.acc[1] = g_box.acc[2] = 0;                                                   \
     g_box.acc[3] = __builtin_amdgcn_s_memrealtime() /* workgroup start, 100 MHz */;                   \
-    st_acc[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */
+    st_acc[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */;     \
+    st_acc[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) /* XCC_ID */
 #define HV_MARK(k)                                                      \
     do {                                                                \
         const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \

@@ -29,6 +29,20 @@
 #pragma once
 #include "hexvec_common.h"
 
+// Diagnostic build (-DHV_QSTAMPS, tools/stamp_step.py): s_memrealtime (100 MHz, one clock for the whole chip) per
+// wavefront at kernel entry / state loaded / step computed (before the state store) / stores retired.  No stamp
+// exists in the product build.
+#ifdef HV_QSTAMPS
+__device__ unsigned long long g_qphase[8192][4];
+#define HV_QPHASE(blk, k)                                                                    \
+    do {                                                                                     \
+        __builtin_amdgcn_s_waitcnt(0);                                                       \
+        if (lane == 0 && (blk) < 8192) g_qphase[blk][k] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#else
+#define HV_QPHASE(blk, k) do { } while (0)
+#endif
+
 namespace hv {
 namespace qpb {
 
@@ -361,6 +375,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     // Lanes past the last env leave now: a group is all live or all dead, nothing below is shared
     // between groups (DPP carries between groups are zero by construction, ballots only ask "any").
     if (!live) return;
+    HV_QPHASE(blk, 0);
 
     LS s;
     s.key = mix32(((u32)env + a.env_offset) * 0x9E3779B9U + a.seed_lo) ^ a.seed_hi;
@@ -397,6 +412,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     }
 
     s.kc = s.key + s.ctr * 0x9E3779B9U;
+    HV_QPHASE(blk, 1);
 
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: F^T order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
@@ -644,6 +660,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     }
 
     // state back to HBM
+    HV_QPHASE(blk, 2);
     rblk[0 * 64 + lane] = s.K0;
     rblk[1 * 64 + lane] = s.K1;
     rblk[2 * 64 + lane] = s.W0;
@@ -666,6 +683,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
         stats[0] = v0;
         stats[1] = v1;
     }
+    HV_QPHASE(blk, 3);
 }
 
 // ---- cold kernels on the state ----
@@ -729,6 +747,13 @@ __global__ __launch_bounds__(256) void k_qpb_stats(const unsigned char *fast, in
 }
 
 } // namespace qpb
+
+#ifdef HV_QSTAMPS
+extern "C" int hexvec_debug_qphases(unsigned long long *host_dst, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_qphase), (size_t)nblocks * 4 * sizeof(unsigned long long));
+}
+#endif
 
 // ---- launchers of this translation unit (HV_QPB_SIZES(X) = the board sizes it instantiates) ----
 template <int N, int ENC, int MODE> static hipError_t qpb_launch1(const KArgs &a, hipStream_t st)

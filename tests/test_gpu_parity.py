@@ -422,7 +422,7 @@ def test_rollout1_at_bench_geometry_every_row_vs_oracle(hx, n, E, enc, first, pl
             if not np.array_equal(got, ref):
                 t, e = np.argwhere((got != ref).reshape(T, E, -1).any(-1))[0]
                 raise AssertionError(f"{k}: launch {launch} (T={T}) first differs at step {t}, env {e} (block {e // 64})")
-        finished += odone.sum(0)
+        finished += odone.sum(0, dtype=np.int64)
         assert np.array_equal(_np(g.episode_stats()), o.episode_stats()), launch
     assert finished.min() >= 3, "every env must have run through several in-kernel resets"
     _same_state(g, o)
