@@ -21,6 +21,15 @@ struct hexvec {
     unsigned char *fast;
     size_t fast_bytes;
     unsigned int *ticket; // hexvec_set_ticket
+    // hexvec_attach_pool
+    long long *pool_slot;
+    unsigned char *pool_ended;
+    unsigned long long *pool_state, *pool_bad;
+    const float *pool_cdf;
+    const int *pool_pos;
+    float pool_prob;
+    int pool_size, pool_npol;
+    uint64_t pool_seed;
 };
 
 static thread_local char g_err[512] = "";
@@ -79,6 +88,20 @@ static KArgs base_args(const hexvec *h)
     a.flags = h->flags;
     a.ticket = h->ticket;
     a.T = 1;
+    if (h->pool_slot) {
+        a.pool_slot = h->pool_slot;
+        a.pool_ended = h->pool_ended;
+        a.pool_ctr = reinterpret_cast<unsigned long long *>(h->fast + h->fast_bytes - 16); // the state's last two words
+        a.pool_state = h->pool_state;
+        a.pool_cdf = h->pool_cdf;
+        a.pool_pos = h->pool_pos;
+        a.pool_bad = h->pool_bad;
+        a.pool_prob = h->pool_prob;
+        a.pool_size = h->pool_size;
+        a.pool_npol = h->pool_npol;
+        a.pool_seed_lo = (u32)h->pool_seed;
+        a.pool_seed_hi = (u32)(h->pool_seed >> 32);
+    }
     return a;
 }
 
@@ -172,6 +195,7 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
     h->hot = nullptr;
     h->stats = nullptr;
     h->fast = nullptr;
+    h->pool_slot = nullptr;
     // auto-reset handles never see a ply after the end of a game: they run on the
     // lane-per-board kernels unless the caller wants the reference's label planes
     h->fast_mode = !(flags & (HEXVEC_F_NO_AUTO_RESET | HEXVEC_F_EXACT_LABELS)) && board_size >= 4;
@@ -182,9 +206,10 @@ extern "C" int hexvec_create(hexvec_t **out, int board_size, int num_envs, int d
         h->qpb = strcmp(ev, "lpb") == 0 ? false : (strcmp(ev, "qpb") == 0 ? true : h->qpb);
     if (h->fast_mode && h->qpb) {
         const int bpw = 64 / hv::qpb_lanes(board_size);
-        const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 32; // + [E][4] 64-bit episode sums
+        // + [E][4] 64-bit episode sums + the two step counters of hexvec_attach_pool (zeroed here, part of the state)
+        const size_t bytes = (size_t)((num_envs + bpw - 1) / bpw) * hv::qpb_block_bytes(board_size) + E * 32 + 16;
         h->fast_bytes = bytes;
-        ok = hipMalloc(&h->fast, bytes) == hipSuccess;
+        ok = hipMalloc(&h->fast, bytes) == hipSuccess && hipMemset(h->fast + bytes - 16, 0, 16) == hipSuccess;
     } else if (h->fast_mode) {
         const int enc = (flags & HEXVEC_F_ENC_B) ? 1 : 0, two = (flags & HEXVEC_F_TWO_SIDED) ? 1 : 0;
         const size_t bytes = (size_t)((num_envs + 63) / 64) * hv::lpb64_block_bytes(board_size, enc, two);
@@ -509,6 +534,32 @@ extern "C" int hexvec_import_state(hexvec_t *h, const void *src, void *stream)
         d += E * hv::HOT_WORDS * 4;
         HV_HIP(hipMemcpyAsync(h->stats, d, E * hv::STAT_WORDS * 8, hipMemcpyDeviceToDevice, st));
     }
+    return HEXVEC_OK;
+}
+
+extern "C" int hexvec_attach_pool(hexvec_t *h, int64_t *slot, uint8_t *ended, float prob_best, int pool_size, uint64_t seed,
+                                  unsigned long long *state2, const float *open_cdf, const int32_t *policy_of_slot,
+                                  int n_policies, unsigned long long *bad_rows)
+{
+    HV_HANDLE(h);
+    if (!slot) {
+        h->pool_slot = nullptr;
+        return HEXVEC_OK;
+    }
+    if (!h->fast_mode || !h->qpb || (h->flags & HEXVEC_F_TWO_SIDED))
+        return fail(HEXVEC_E_MODE, "%s", "hexvec_attach_pool needs an auto-reset self-play handle on the default layout");
+    if (!ended || !state2 || pool_size < 1 || n_policies < 1 || !(prob_best >= 0.0f && prob_best <= 1.0f))
+        return fail(HEXVEC_E_ARG, "%s", "hexvec_attach_pool: ended / state2 NULL, pool_size or n_policies < 1, or prob_best outside [0, 1]");
+    h->pool_slot = (long long *)slot;
+    h->pool_ended = ended;
+    h->pool_state = state2;
+    h->pool_bad = bad_rows;
+    h->pool_cdf = open_cdf;
+    h->pool_pos = policy_of_slot;
+    h->pool_prob = prob_best;
+    h->pool_size = pool_size;
+    h->pool_npol = n_policies;
+    h->pool_seed = seed;
     return HEXVEC_OK;
 }
 

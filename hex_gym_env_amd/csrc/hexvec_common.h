@@ -45,7 +45,19 @@ struct KArgs {
     int phase;              // M_STEP on self-play handles: 0 whole step, 1 agent ply only, 2 opponent plies only
     unsigned char *pending; // split step: 1 = reply owed, 2 = opening owed
     unsigned int *ticket;   // literal-engine handles: completion ticket in host-pinned memory (hexvec_set_ticket)
+    // hexvec_attach_pool (split step on bitboard handles): setup_opponents + openings in the launch's tail
+    long long *pool_slot;   // NULL = not attached
+    unsigned char *pool_ended;
+    unsigned long long *pool_ctr; // handle-owned {steps as the agent's launches read it, as the opponent's launches read it}
+    unsigned long long *pool_state; // the caller's draw counter: written by the opponent's launch
+    const float *pool_cdf;
+    const int *pool_pos;
+    unsigned long long *pool_bad;
+    float pool_prob;
+    int pool_size, pool_npol;
+    u32 pool_seed_lo, pool_seed_hi;
 };
+
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ u32 mix32(u32 x)
@@ -65,6 +77,22 @@ __device__ __forceinline__ float gumbel_from_hash(u32 h)
     const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float e = -__builtin_amdgcn_logf(u);                            // -log2(u)
     return __builtin_fmaf(-0.69314718f, __builtin_amdgcn_logf(e), 0.36651292f); // -ln(ln2 * e)
+}
+// the counter hash of hexvec_pick_opponents / hexvec_sample_masked: one key per (seed, salt, counter, row)
+__device__ __forceinline__ u32 row_key(u32 row, unsigned long long ctr, u32 seed_lo, u32 seed_hi, u32 salt)
+{
+    return mix32((row + (u32)ctr * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ ((u32)(ctr >> 32) * 0xC2B2AE35U) ^
+           mix32(salt * 0x27D4EB2FU + 0x165667B1U);
+}
+// SelfPlayEnv.setup_opponents (SelfplayWrapper.py:97-104) for one board: the best model with probability prob_best,
+// else a uniformly drawn pool member
+__device__ __forceinline__ long long pick_slot(u32 row, unsigned long long ctr, u32 seed_lo, u32 seed_hi, u32 salt,
+                                               float prob_best, int pool_size)
+{
+    const u32 k = row_key(row, ctr, seed_lo, seed_hi, salt);
+    const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const u32 member = __umulhi(mix32(k + 0x9E3779B9U), (u32)pool_size);
+    return u < prob_best ? -1LL : (long long)member;
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u32 rflu(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }

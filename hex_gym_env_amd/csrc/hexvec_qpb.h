@@ -458,9 +458,10 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     };
     // The same opponent ply on a board that is known to be EMPTY (just reset inside this kernel):
     // the k-th empty cell is cell k and the stone has no neighbours: nothing to search or flood.
-    auto opening_on_empty = [&]() {
-        const u32 r = QQ::draw(s);
-        const int act = (int)__umulhi(r, (u32)C); // n_empty == C
+    // (ext >= 0: the caller's action -- nothing is drawn from the board's own stream, as for any external action)
+    auto opening_on_empty = [&](int ext) {
+        int act = ext;
+        if (ext < 0) act = (int)__umulhi(QQ::draw(s), (u32)C); // n_empty == C
         const int p = s.cur, fr = B ? p : 1;      // B: the mover's frame; hex-v0: the opponent's view
         const int yf = act / N, xf = act - yf * N, at = xf * N + yf;
         const int idx0 = fr ? at : act, idx1 = fr ? act : at;
@@ -577,6 +578,54 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             const bool dn = fin && s.done;
             handle_done(dn, won, tobs_row);
             if (dn && opens) s.pend = 2; // the opponent opens on the fresh board
+            if (a.pool_slot) {
+                // hexvec_attach_pool: SelfPlayEnv.setup_opponents (SelfplayWrapper.py:97-104) for the boards that
+                // start a new episode here -- exactly the boards and draws of hexvec_pick_opponents(when = 3, salt 1)
+                // behind the agent's launch / (when = 4, salt 4) behind the opponent's.  The step counter comes from
+                // the handle's own two words: each launch reads the one the OTHER phase writes, so no launch reads a
+                // word it writes.
+                const unsigned long long nstep = a.pool_ctr[a.phase == 1 ? 0 : 1];
+                const bool first_half = a.phase == 1;
+                if (first_half && wr) a.pool_ended[o] = dn ? 1 : 0;
+                // a board qualifies at one point at most: ended and the agent moves first on the fresh board
+                // (salt 1 after the agent's ply, 5 after the reply), or a fresh board on which the opponent is about
+                // to open (salt 2 / 4)
+                const bool opp_opens = s.pend == 2 && (first_half || dn);
+                const bool sel = opp_opens || (dn && s.pend == 0);
+                long long nslot = 0;
+                if (sel) {
+                    const u32 salt = first_half ? (opp_opens ? 2u : 1u) : (opp_opens ? 4u : 5u);
+                    nslot = pick_slot((u32)env, nstep, a.pool_seed_lo, a.pool_seed_hi, salt, a.pool_prob, a.pool_size);
+                    if (wr) a.pool_slot[o] = nslot;
+                }
+                if (!first_half) {
+                    // the opening of a board that ended on the reply, from the picked opponent's cumulative opening
+                    // distribution on the empty board (SelfplayWrapper.py:79-80): first cell whose entry exceeds u
+                    if (a.pool_cdf && opp_opens) {
+                        int pol = a.pool_pos ? a.pool_pos[min(max((int)nslot + 1, 0), a.pool_size)] : 0;
+                        pol = min(max(pol, 0), a.pool_npol - 1);
+                        const float *cdf = a.pool_cdf + (size_t)pol * C;
+                        const u32 k = row_key((u32)env, nstep + 1ULL, a.pool_seed_lo, a.pool_seed_hi, 6u);
+                        const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        u32 below = 0; // cells of this lane's share whose entry is <= u
+                        for (int cc = c.l; cc < C; cc += L) below += cdf[cc] <= u ? 1u : 0u;
+                        if (L >= 2) below += dpp0<DPP_QUAD_XOR1>(below);
+                        if (L >= 4) below += dpp0<DPP_QUAD_XOR2>(below);
+                        if (L >= 8) below += dpp0<DPP_HALF_MIRROR>(below);
+                        if (L >= 16) below += dpp0<DPP_ROW_MIRROR>(below);
+                        const bool bad = !(cdf[C - 1] == 1.0f); // not a distribution (a NaN logit): cell 0, counted
+                        if (bad && wr && a.pool_bad) atomicAdd(a.pool_bad, 1ULL);
+                        opening_on_empty(bad ? 0 : (int)min(below, (u32)(C - 1)));
+                        s.pend = 0;
+                    }
+                    if (blk == 0 && lane == 0) { // the step is complete: publish its number for the sampling calls
+                        a.pool_ctr[0] = nstep + 1ULL;
+                        *a.pool_state = nstep + 1ULL;
+                    }
+                } else if (blk == 0 && lane == 0) {
+                    a.pool_ctr[1] = nstep;
+                }
+            }
             if (wr && a.pending) a.pending[o] = (unsigned char)s.pend;
             do_emit(a.obs ? a.obs + (size_t)e0 * C : nullptr, a.legal ? a.legal + (size_t)e0 * C : nullptr);
         } else
@@ -647,7 +696,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                 const bool dn2 = reply && s.done;
                 handle_done(dn2, won, tobs_row);
                 // ---- slot 3: openings of the boards that ended on the reply
-                if (dn2 && opens) opening_on_empty();
+                if (dn2 && opens) opening_on_empty(-1);
             }
             if (wr) {
                 if (a.reward) a.reward[o] = (float)rew;

@@ -45,11 +45,9 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long
         return;
     }
     const unsigned long long ctr = state[0];
-    const u32 c_lo = (u32)ctr, c_hi = (u32)(ctr >> 32);
     const size_t base = (size_t)row * (size_t)cols;
     const size_t lbase = (size_t)row * (size_t)logits_row_stride; // stride 0: every board shares one logits row
-    const u32 rkey = mix32(((u32)row + c_lo * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ (c_hi * 0xC2B2AE35U) ^
-                     mix32(salt * 0x27D4EB2FU + 0x165667B1U);
+    const u32 rkey = row_key((u32)row, ctr, seed_lo, seed_hi, salt);
     float best = -INFINITY;
     int besti = 0x7fffffff;
     bool bad = false;
@@ -124,12 +122,7 @@ __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int whe
         if (sel && when == 4) salt += 1u;
     }
     if (!sel) return;
-    const unsigned long long ctr = state[0];
-    const u32 k = mix32(((u32)e + (u32)ctr * 0x85EBCA6BU) * 0x9E3779B9U + seed_lo) ^ seed_hi ^ ((u32)(ctr >> 32) * 0xC2B2AE35U) ^
-                  mix32(salt * 0x27D4EB2FU + 0x165667B1U);
-    const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const u32 member = __umulhi(mix32(k + 0x9E3779B9U), (u32)pool_size);
-    slot[e] = u < prob_best ? -1LL : (long long)member;
+    slot[e] = pick_slot((u32)e, state[0], seed_lo, seed_hi, salt, prob_best, pool_size);
 }
 
 } // namespace hv

@@ -553,6 +553,13 @@ class VecSelfPlayEnv:
         self._pick_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0xD1B54A32D192ED03) & (2 ** 64 - 1)
         self._empty_board = torch.zeros((num_envs, board_size, board_size), dtype=torch.int8, device=self.device)
         self._all_legal = torch.ones((num_envs, board_size * board_size), dtype=torch.uint8, device=self.device)
+        # hexvec_attach_pool: the slot choice and the openings ride in the tails of the two env launches of a step
+        # (fuse_pool = False keeps them as launches of their own: the form the fused one is tested against)
+        self.fuse_pool = True
+        self._attached = None           # fingerprint of what the handle currently holds
+        self._open_cdf = None           # float32 [n_policies, cells]: static buffer (captured graphs read it)
+        self._open_cdf_versions = None
+        self._open_bad = torch.zeros((), dtype=torch.long, device=self.device)
 
     # the reference's attribute names
     opponent_models = property(lambda self: self.buffer.members)
@@ -703,6 +710,85 @@ class VecSelfPlayEnv:
             obs, legal, pending = new
         return obs, legal, pending, handled
 
+    # -- hexvec_attach_pool ---------------------------------------------------
+    def _opening_policies(self):
+        """(policies, policy_of_slot int32 [pool + 1] or None) if every pool member has an opening DISTRIBUTION the
+        library can tabulate (an actor network's logits on the empty board, or uniform), else None"""
+        tab = self._pool_table()
+        if tab is not None:
+            return tab.policies, (tab.policy_of_slot if len(tab.policies) > 1 else None)
+        groups = list(self._groups().values())
+        if not all(hasattr(pol, "opening_logits") or isinstance(pol, RandomLegalPolicy) for pol, _ in groups):
+            return None
+        if len(groups) == 1:
+            return [groups[0][0]], None
+        key = tuple(id(pol) for pol, _ in groups)
+        if getattr(self, "_pos_key", None) != key:
+            pos = [0] * (len(self.buffer) + 1)
+            for g, (_, slots) in enumerate(groups):
+                for k in slots:
+                    pos[k + 1] = g
+            self._pos, self._pos_key = torch.tensor(pos, dtype=torch.int32, device=self.device), key
+        return [pol for pol, _ in groups], self._pos
+
+    @torch.no_grad()
+    def _refresh_open_cdf(self, policies):
+        """cumulative opening distribution per policy (softmax of its logits on the empty board; one-hot at the
+        arg-max for a deterministic policy; uniform for the random policy), rebuilt in place when a network changed"""
+        C = self.board_size * self.board_size
+        vers = [pol.weights_version() if hasattr(pol, "weights_version") else None for pol in policies]
+        if self._open_cdf is None or self._open_cdf.shape[0] != len(policies):
+            self._open_cdf = torch.empty((len(policies), C), dtype=torch.float32, device=self.device)
+            self._open_cdf_versions = None
+        if vers == self._open_cdf_versions:
+            return self._open_cdf
+        for u, pol in enumerate(policies):
+            if hasattr(pol, "opening_logits"):
+                z = pol.opening_logits().reshape(-1).to(self.device, torch.float64)
+                if getattr(pol, "deterministic", False):
+                    p = torch.zeros(C, dtype=torch.float64, device=self.device)
+                    p[z.argmax()] = 1.0
+                    p = torch.where(torch.isnan(z).any(), torch.full_like(p, float("nan")), p)
+                else:
+                    p = torch.softmax(z, 0)
+            else:
+                p = torch.full((C,), 1.0 / C, dtype=torch.float64, device=self.device)
+            cdf = p.cumsum(0).to(torch.float32)
+            # the library's contract: the last entry is exactly 1 for a distribution, anything else marks a row
+            # that cannot be sampled (a NaN logit): such boards open at cell 0 and are counted
+            ok = torch.isfinite(cdf).all()
+            cdf[-1] = torch.where(ok, torch.ones((), device=self.device), torch.full((), float("nan"), device=self.device))
+            self._open_cdf[u].copy_(cdf)
+        self._open_cdf_versions = vers
+        return self._open_cdf
+
+    def _attach_pool(self):
+        """make the handle's split step do setup_opponents (and, where the pool allows, the openings) itself;
+        returns (attached, openings_inside)"""
+        import ctypes as C
+        from . import _lib
+        want = self.fuse_pool and not self.buffer.evaluating and not self.sample_board
+        if not want:
+            if self._attached is not None:
+                _lib.check(_lib.lib().hexvec_attach_pool(self.vec._h, None, None, C.c_float(0.0), 1, C.c_uint64(0), None,
+                                                         None, None, 1, None))
+                self._attached = None
+            return False, False
+        op = self._opening_policies()
+        cdf = pos = None
+        if op is not None:
+            cdf, pos = self._refresh_open_cdf(op[0]), op[1]
+        key = (float(self.buffer.prob_best), len(self.buffer), None if cdf is None else cdf.data_ptr(),
+               None if pos is None else pos.data_ptr(), self.slot.data_ptr())
+        if key != self._attached:
+            p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            _lib.check(_lib.lib().hexvec_attach_pool(
+                self.vec._h, p(self.slot), p(self._ended), C.c_float(self.buffer.prob_best), len(self.buffer),
+                C.c_uint64(self._pick_seed), p(self._pick_state), p(cdf), p(pos),
+                1 if cdf is None else int(cdf.shape[0]), p(self._open_bad)))
+            self._attached = key
+        return True, cdf is not None
+
     # -- gym-like API ----------------------------------------------------------
     def reset(self):
         """SelfPlayEnv.reset for every board (:69-89): new opponent, then it opens where the agent
@@ -726,9 +812,21 @@ class VecSelfPlayEnv:
         Finished boards are reset (with a fresh random position if sample_board); their opponent is
         re-drawn before it opens (if it opens).  No host synchronisation: the number of opponent
         rounds is fixed (replies, then openings if any agent plays WHITE)."""
+        attached, openings_inside = self._attach_pool()
         if self.buffer.evaluating or self.sample_board:
             return self._step_general(actions)
-        # the common case: every slot update is one fused launch, the boards that owe no ply are skipped
+        if attached:
+            # two env launches and one policy launch: the slot choice of every board that starts a new episode, the
+            # step counter and (openings_inside) the openings of the boards that ended on the reply ride in the tails
+            # of hexvec_step_agent / hexvec_step_opponent -- same boards and same draws as the launches below
+            obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
+            self._opponent_actions(obs, legal, pending, rng=self._rng(3))   # replies (+ openings of boards that just ended)
+            self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+            if self._any_white and not openings_inside:     # a pool member without a tabulated opening distribution
+                self._opening_actions(rng=self._rng(6), pending=self.vec.pending)
+                self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+            return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
+        # the same step with every slot update as a launch of its own, the boards that owe no ply are skipped
         # inside the sampler, nothing else is computed on the host side of the ABI
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
         # (all draws of the step share one device counter under salts 1..6; the last call advances it)
@@ -771,7 +869,8 @@ class VecSelfPlayEnv:
         """everything host-side that a captured collection step bakes in: the pool's policy objects and
         their grouping, the evaluation flag, the 80/20 split"""
         b = self.buffer
-        return (id(b.best), tuple(map(id, b.members)), bool(b.evaluating), float(b.prob_best), self._any_white)
+        return (id(b.best), tuple(map(id, b.members)), bool(b.evaluating), float(b.prob_best), self._any_white,
+                bool(self.fuse_pool))
 
     def capture_collect_step(self, agent_policy, warmup=3):
         """Capture  actions = agent_policy.choose_actions(obs, legal); step(actions)  as ONE hipGraph
@@ -835,6 +934,9 @@ class VecSelfPlayEnv:
             for pol in uniq:
                 if hasattr(pol, "sync_weights"):
                     pol.sync_weights()
+            op = self._opening_policies() if self._attached is not None else None
+            if op is not None:
+                self._refresh_open_cdf(op[0])       # in place: the captured launches read this buffer
             holder["weights"] = vers
 
         def run():
@@ -854,7 +956,7 @@ class VecSelfPlayEnv:
         """number of sampling rows so far that had no legal cell or a non-finite logit (sample_masked),
         over the pool's policies (+ any given, e.g. the agent's); one host read.  Always 0 in a healthy
         run: boards handed to a policy always have an empty cell."""
-        seen, tot = set(), 0
+        seen, tot = set(), int(self._open_bad.item())
         for pol in [self.buffer.policy(k) for k in range(-1, len(self.buffer))] + list(more_policies):
             c = getattr(pol, "_bad_rows", None)
             if c is not None and id(c) not in seen:

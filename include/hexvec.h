@@ -256,6 +256,34 @@ int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *done, const ui
                           const uint8_t *white, int rows, float prob_best, int pool_size, uint64_t seed,
                           uint32_t salt, int advance, unsigned long long *state2, void *stream);
 
+/* SelfPlayEnv.setup_opponents and the opponents' openings INSIDE the split step (SelfplayWrapper.py:75, :79-80,
+ * :97-104): after this call hexvec_step_agent / hexvec_step_opponent of the handle do, in the tail of their own
+ * launch, what hexvec_pick_opponents does as a launch of its own (same boards, same draws):
+ *   hexvec_step_agent     = ... + hexvec_pick_opponents(when = 3, salt 1)
+ *   hexvec_step_opponent  = ... + hexvec_pick_opponents(when = 4, salt 4) + the counter moves on
+ * and, if open_cdf != NULL, hexvec_step_opponent also PLAYS the opening of every board that ended on the reply and
+ * on which the opponent moves first (pending would be 2), drawn from the picked opponent's opening distribution on
+ * the empty board -- so one hexvec_step_agent + one hexvec_step_opponent complete a step and no board is left
+ * pending.  Bookkeeping, all device memory owned by the caller and alive while attached:
+ *   slot   int64 [E]   opponent slot per board (-1 = best model, k = pool member k), read and written;
+ *   ended  uint8 [E]   scratch ("ended on the agent's ply");
+ *   state2             the caller's draw counter {counter, reserved} (hexvec_sample_masked / hexvec_mlp_actions):
+ *                      only WRITTEN here -- hexvec_step_opponent publishes the number of completed steps, so the
+ *                      sampling calls of the next step draw under a new counter without a launch of their own; the
+ *                      picks read the handle's own copy (part of the exported state);
+ *   open_cdf float32 [n_policies, cells] or NULL: per policy, the cumulative distribution of its opening on the
+ *                      empty board, non-decreasing, last entry exactly 1.0f (any other last entry marks a policy
+ *                      that cannot be sampled: its boards open at cell 0 and are counted in *bad_rows); the opening is
+ *                      the first cell whose entry exceeds u, u uniform in (0, 1) from the counter hash of
+ *                      (seed, salt 6, steps + 1, board);
+ *   policy_of_slot int32 [pool_size + 1] or NULL (= policy 0): the policy index of slot -1, 0, 1, ...;
+ *   bad_rows uint64 or NULL.
+ * slot == NULL detaches.  Auto-reset self-play handles on the default layout only (HEXVEC_E_MODE otherwise).
+ * A host-side setting: nothing is enqueued; launches enqueued earlier keep what they were given. */
+int hexvec_attach_pool(hexvec_t *h, int64_t *slot, uint8_t *ended, float prob_best, int pool_size, uint64_t seed,
+                       unsigned long long *state2, const float *open_cdf, const int32_t *policy_of_slot,
+                       int n_policies, unsigned long long *bad_rows);
+
 /* The opponents' (or the agent's) actor network evaluated, masked and sampled for a batch of boards in one call:
  * OpponentPolicy.choose_action -> model.predict(board, deterministic, action_masks=mask) (SelfplayWrapper.py:26-35)
  * for SB3's default MlpPolicy actor  flatten -> float -> Linear(cells, h1)-Tanh-Linear(h1, h2)-Tanh-Linear(h2, cells)

@@ -950,3 +950,120 @@ def test_sb3_style_models_run_on_the_fused_kernel_as_live_views(hx):
     # a different architecture: predict() adapter
     odd = _FakeSb3Model(n * n, hidden=(64, 64, 64))
     assert isinstance(as_policy(odd, "cuda"), PredictAdapter)
+
+
+# ---- hexvec_attach_pool: setup_opponents and the openings in the tails of the split step's own launches ----
+@pytest.mark.parametrize("agent,openings", [(0, "none"), (None, "launch"), (1, "launch")],
+                         ids=["agents-black", "mixed-colours", "agents-white"])
+def test_attached_pool_equals_the_separate_pick_launches(hx, agent, openings):
+    """SelfPlayEnv.setup_opponents (SelfplayWrapper.py:97-104) folded into hexvec_step_agent / hexvec_step_opponent
+    (hexvec_attach_pool) picks the same boards with the same draws as hexvec_pick_opponents as launches of its own,
+    and publishes the same draw counter: two envs, same seed, sampled (not arg-max) opponents from a pool of two
+    networks -- every output of every step, the slot array and the counter are equal.  (The openings stay a launch
+    of their own here; inside the step they are drawn differently, see the next test.)"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    n, E = 5, 2048
+    torch.manual_seed(3)
+    nets = [MlpActorPolicy(n * n).cuda() for _ in range(2)]
+
+    def make(fused):
+        env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=6, base_model=nets[0], seed=11, agent_player_num=agent)
+        env.set_opponent_model(3, nets[1], 0.1)         # a second network in the pool (not the best model)
+        env.fuse_pool = fused
+        if fused:
+            env._opening_policies = lambda: None        # picks and counter in the step's tails, openings as a launch
+        return env
+
+    ea, eb = make(True), make(False)
+    oa, la = ea.reset()
+    ob, lb = eb.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ended = 0
+    for t in range(60):
+        act = torch.multinomial(la.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        ra, rb = ea.step(act), eb.step(act)
+        assert ea._attached is not None and eb._attached is None
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert torch.equal(x, y), (t, k)
+        assert torch.equal(ea.slot, eb.slot), t
+        assert torch.equal(ea._pick_state, eb._pick_state) and int(ea._pick_state[0]) == t + 1
+        assert int(ea.vec.pending.sum()) == 0
+        la = ra[3]
+        ended += int(ra[2].sum())
+    assert ended > 3 * E and len(set(ea.slot.tolist())) == 7          # -1 and all six members were drawn
+    assert ea.degenerate_rows() == 0 and eb.degenerate_rows() == 0
+
+
+def test_openings_inside_the_step_follow_each_opponents_opening_distribution(hx):
+    """with an opening distribution per pool member (hexvec_attach_pool(open_cdf)), ONE hexvec_step_agent + ONE
+    hexvec_step_opponent complete a step: a board that ends on the reply gets its new opponent and that opponent's
+    opening inside the same launch (SelfplayWrapper.py:75, :79-80).  All agents WHITE: every fresh board shows exactly
+    the opening stone; per pool member the empirical opening frequencies match softmax(logits(empty board)) -- a
+    sampled network, an arg-max network (always its best cell) and the uniform random policy."""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy, RandomLegalPolicy
+    n, E, C = 4, 16384, 16
+    torch.manual_seed(8)
+    sampled, greedy = MlpActorPolicy(C).cuda(), MlpActorPolicy(C, deterministic=True).cuda()
+    with torch.no_grad():
+        sampled.action_net.bias.mul_(0).add_(torch.linspace(-1.5, 1.5, C, device="cuda"))      # a clearly non-uniform opening
+    env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=4, base_model=sampled, seed=2, agent_player_num=1,
+                         prob_best=0.4)
+    env.set_opponent_model(1, greedy, 0.0)
+    env.set_opponent_model(2, RandomLegalPolicy(env._gen), 0.0)
+    assert env.best_model is sampled and env._pool_table() is None and len(env._groups()) == 3
+    env.reset()
+    counts = {k: torch.zeros(C, dtype=torch.long, device="cuda") for k in ("sampled", "greedy", "random")}
+    kind_of_slot = {-1: "sampled", 0: "sampled", 1: "greedy", 2: "random", 3: "sampled"}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    legal = env.vec.legal
+    launches = []
+    for t in range(50):
+        act = torch.multinomial(legal.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        obs, rew, done, legal, win = env.step(act)
+        launches.append(env.vec.last_kernel())
+        assert env._attached is not None and int(env.vec.pending.sum()) == 0
+        o = obs.reshape(E, n, n)
+        fresh = done != 0
+        assert bool(((o[fresh] != 0).sum((1, 2)) == 1).all()) and bool(((o[fresh] == 1).sum((1, 2)) == 1).all())
+        # the opponent (BLACK) chose its cell in ITS view; the WHITE agent sees the transposed board
+        cell = (o[fresh].transpose(1, 2).reshape(-1, C) == 1).float().argmax(1)
+        slots = env.slot[fresh]
+        for s, kind in kind_of_slot.items():
+            counts[kind] += torch.bincount(cell[slots == s], minlength=C)
+    tot = {k: int(v.sum()) for k, v in counts.items()}
+    assert min(tot.values()) > 10000, tot
+    p = torch.softmax(sampled.opening_logits().reshape(-1).double(), 0)
+    f = counts["sampled"].double() / tot["sampled"]
+    assert float((f - p).abs().max()) < 4.0 * float((p * (1 - p) / tot["sampled"]).sqrt().max()) + 1e-3
+    best = int(greedy.opening_logits().argmax())
+    assert int(counts["greedy"][best]) == tot["greedy"]
+    f = counts["random"].double() / tot["random"]
+    assert float((f - 1.0 / C).abs().max()) < 4.0 * (1.0 / C / tot["random"]) ** 0.5 + 1e-3
+    assert env.degenerate_rows() == 0
+    # a network whose opening cannot be sampled (a NaN logit) is counted, never silent
+    with torch.no_grad():
+        sampled.action_net.bias[3] = float("nan")
+    before = env.degenerate_rows()
+    for t in range(3):
+        act = torch.multinomial(legal.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        legal = env.step(act)[3]
+    assert env.degenerate_rows() > before
+
+
+def test_attach_pool_rejects_other_handles(hx):
+    import ctypes as C
+    L = hx._lib.lib()
+    slot = torch.zeros(8, dtype=torch.long, device="cuda")
+    ended = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    st = torch.zeros(2, dtype=torch.long, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for kw in (dict(rollout_layout=True), dict(two_sided=True), dict(auto_reset=False)):
+        env = hx.HexVecEnv(5, 8, encoding="B", **kw)
+        rc = L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(0.8), 4, C.c_uint64(1), p(st), None, None, 1, None)
+        assert rc == -4, kw
+    env = hx.HexVecEnv(5, 8, encoding="B")
+    assert L.hexvec_attach_pool(env._h, p(slot), None, C.c_float(0.8), 4, C.c_uint64(1), p(st), None, None, 1, None) == -1
+    assert L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(1.5), 4, C.c_uint64(1), p(st), None, None, 1, None) == -1
+    assert L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(0.8), 4, C.c_uint64(1), p(st), None, None, 1, None) == 0
+    assert L.hexvec_attach_pool(env._h, None, None, C.c_float(0.0), 1, C.c_uint64(0), None, None, None, 1, None) == 0
