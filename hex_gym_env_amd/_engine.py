@@ -158,6 +158,7 @@ def acquire(board_size, encoding, device=None):
     for eng in engines:
         if not eng._busy:
             eng._busy = True
+            eng._st = eng.env._stream()     # the NEW user's current stream (the first user's may be gone)
             return eng
     eng = _BoardEngine(board_size, encoding, device)
     eng._busy = True

@@ -50,6 +50,8 @@
 // Included by hexvec_lpb64.hip with HV_BPW = 64 boards per wavefront (every lane owns a board;
 // 32 was measured in round 1: same time, the per-lane part doubles) and HV_LPB_NAME(x) = lpb64_##x.
 #pragma once
+#include <stdlib.h>
+
 #include "hexvec_common.h"
 
 // Diagnostic build (-DHV_STAMPS, tools/stamp_rollout.py): s_memtime stamps around the sections of a
@@ -235,6 +237,58 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         s.ctr += 1;
         return r;
     }
+    // Work that place() runs in the shadow of its LDS round trips (the playing wavefront is alone on its SIMD: what
+    // it does not overlap itself is exposed).  NoFill: nothing.  NextDraw: the action of whoever moves NEXT, drawn
+    // speculatively from the board as this stone leaves it -- a() once the stone's bits are cleared (covers the six
+    // neighbour reads), b() behind the first hop of the chase.  The draw is not consumed here: the caller commits it
+    // (commit_draw) only where that player really moves next, so the per-board draw sequence stays the plain one.
+    struct NoFill {
+        static constexpr bool ON = false;
+        __device__ __forceinline__ void a(const LS &) {}
+        __device__ __forceinline__ void b() {}
+    };
+    struct NextDraw {
+        static constexpr bool ON = true;
+        int f; // frame of the next mover's action (0: F order, 1: FT order)
+        u32 k, word;
+        int widx, act;
+        __device__ __forceinline__ void a(const LS &s)
+        { // the word that holds the k-th empty cell (kth_set, first half)
+            const u32 r = mix32(s.kc);
+            k = s.n_empty > 0 ? __umulhi(r, (u32)s.n_empty) : 0u;
+            u32 base = 0, c = 0;
+            word = f ? s.E1[0] : s.E0[0];
+            widx = 0;
+#pragma unroll
+            for (int j = 0; j + 1 < JW; ++j) {
+                c += (u32)__popc(f ? s.E1[j] : s.E0[j]);
+                const bool past = k >= c;
+                word = past ? (f ? s.E1[j + 1] : s.E0[j + 1]) : word;
+                base = past ? c : base;
+                widx = past ? j + 1 : widx;
+            }
+            k -= base;
+        }
+        __device__ __forceinline__ void b()
+        { // its position in that word (kth_set, second half)
+            int pos = 0;
+            u32 kk = k, w = word;
+#pragma unroll
+            for (int sh = 16; sh >= 1; sh >>= 1) {
+                const u32 cl = (u32)__popc(w & ((1u << sh) - 1u));
+                const bool up = kk >= cl;
+                kk = up ? kk - cl : kk;
+                w = up ? w >> sh : w;
+                pos += up ? sh : 0;
+            }
+            act = widx * 32 + pos;
+        }
+    };
+    static __device__ __forceinline__ void commit_draw(LS &s)
+    {
+        s.kc += 0x9E3779B9U;
+        s.ctr += 1;
+    }
     // uniform-legal action in frame f's row-major order (SelfplayWrapper.py:16-22 shape)
     static __device__ __forceinline__ int rng_action(LS &s, int f)
     {
@@ -274,8 +328,9 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
 
     // One legal stone of colour p at idx0 (F order) == idx1 (FT order).  Returns
     // true iff p now connects its two edges (HexGame.py:98-105 via connectivity).
+    template <class Fill>
     static __device__ __forceinline__ bool place(unsigned char *lds, LS &s, int idx0, int idx1, int p, int y, int x,
-                                                 int lane, StampBox &box)
+                                                 int lane, StampBox &box, Fill &fill)
     { // (y, x): coordinates of the stone in p's own frame
         HV_PMARK0(box);
         // union-find in p's own frame: issue the six neighbour reads first, their LDS latency is
@@ -299,6 +354,7 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         clear_bit(s.E1, idx1);
         s.n_empty -= 1;
         put_stone(lds, s, idx0, idx1, p, lane);
+        fill.a(s);
         HV_PMARK(box, 0); // neighbour reads issued, bitboards / image updated
         // Stones of p on consecutive ring cells touch each other, so they already share a root: ONE cell
         // per run of p-stones around the ring represents its group, and there are at most three runs.
@@ -318,6 +374,14 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
             e[k] = s1 ? e6[2 * k + 1] : (s0 ? e6[2 * k] : 0u);
         }
         // follow child pointers to the roots (all chains of all lanes together)
+        if (Fill::ON) { // the first hop is issued unconditionally (a lane without a child pointer re-reads its cell)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ix[i] = (e[i] - 1u) < 0xDFu ? (int)e[i] - 1 : ix[i];
+                e[i] = uf[ix[i]];
+            }
+            fill.b();
+        }
         for (;;) {
             bool any = false;
             bool ch[3];
@@ -477,16 +541,21 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
     static __device__ __forceinline__ void finish(const Snap &sn, u64 view1, signed char *obs, unsigned char *legal,
                                                   int lane)
     {
+        // streamed once, never re-read by this kernel: non-temporal stores (plain stores: +13...+25 % per step at
+        // 11x11 / 65 536).  All observation pieces first, then all mask pieces: 1-2 % faster than alternating between
+        // the two arrays piece by piece (tools/ab_inproc.py, same process, same buffers, six placements).
+        typedef u32 __attribute__((ext_vector_type(4))) v4u;
 #pragma unroll
-        for (int it = 0; it < G::NIT; ++it) {
-            const int byte0 = (it * 64 + lane) * 16;
-            uint4 o, l;
-            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], TWOV ? sn.r1[it] : sn.r0[it], o, l);
-            if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
-                // streamed once, never re-read by this kernel: non-temporal stores
-                typedef u32 __attribute__((ext_vector_type(4))) v4u;
-                if (OBS) __builtin_nontemporal_store(v4u{o.x, o.y, o.z, o.w}, reinterpret_cast<v4u *>(obs + byte0));
-                if (LEGAL) __builtin_nontemporal_store(v4u{l.x, l.y, l.z, l.w}, reinterpret_cast<v4u *>(legal + byte0));
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int it = 0; it < G::NIT; ++it) {
+                const int byte0 = (it * 64 + lane) * 16;
+                uint4 o, l;
+                merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], TWOV ? sn.r1[it] : sn.r0[it], o, l);
+                if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
+                    if (OBS && pass == 0) __builtin_nontemporal_store(v4u{o.x, o.y, o.z, o.w}, reinterpret_cast<v4u *>(obs + byte0));
+                    if (LEGAL && pass == 1) __builtin_nontemporal_store(v4u{l.x, l.y, l.z, l.w}, reinterpret_cast<v4u *>(legal + byte0));
+                }
             }
         }
     }
@@ -548,7 +617,9 @@ template <int N, int ENC, int BPW, int VIEWS> struct FastState {
 // HELPER = 1: 128-thread workgroups.  Wave 0 plays; wave 1 only copies observations: at every emission
 // point wave 0 publishes the view mask and meets wave 1 at a barrier, wave 1 snapshots the images into
 // registers, a second barrier releases wave 0, and wave 1 merges and stores while wave 0 computes on.
-template <int N, int ENC, int MODE, int BPW, int HELPER, int VIEWS>
+// SPEC = 1 (self-play rollout only): the opponent's reply is drawn inside the agent's ply (Lpb::NextDraw).  Same
+// results; which form is faster depends on what bounds the launch (lpb_launch2).
+template <int N, int ENC, int MODE, int BPW, int HELPER, int VIEWS, int SPEC = 0>
 __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 {
     using L = Lpb<N, ENC, BPW, VIEWS>;
@@ -572,7 +643,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     unsigned char *sblk = a.fast + (size_t)blk * FastState<N, ENC, BPW, VIEWS>::BLOCK_BYTES;
     u32 *rblk = reinterpret_cast<u32 *>(sblk + L::LDS_BYTES);
     u32 *hblk = reinterpret_cast<u32 *>(sblk + FastState<N, ENC, BPW, VIEWS>::HI_OFF);
-    const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
+    // (the self-play rollout is launched on self-play handles only, the two-sided one on two-sided handles: lpb_launch1)
+    const bool two = MODE == M_ROLLOUT1 ? false : (MODE == M_ROLLOUT2 ? true : (a.flags & HEXVEC_F_TWO_SIDED) != 0);
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
     const bool vec_ok = ((size_t)a.E * C) % 16 == 0;
@@ -687,7 +759,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     // one ply by the player to move; `act` is in the frame `fr` (0: F order, 1: FT order).
     // Returns the reference's make_move code: -1 none, 0/1 winner, 3 illegal.
     // check = false for actions the library drew itself (always legal).
-    auto ply = [&](int act, int fr, bool check) -> int {
+    typename L::NoFill nofill;
+    auto ply_f = [&](int act, int fr, bool check, auto &fill) -> int {
         const bool inb = !check || (unsigned)act < (unsigned)C;
         const int yf = inb ? act / N : 0, xf = inb ? act - yf * N : 0;
         const int at = xf * N + yf;
@@ -695,7 +768,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         if (check && (!inb || !L::test_bit(s.E0, idx0))) return 3;
         const int p = s.cur;
         const bool same = p == fr; // the plane of colour p is indexed in p's own frame
-        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane, g_box) || ((s.prewon >> p) & 1);
+        const bool win = L::place(lds, s, idx0, idx1, p, same ? yf : xf, same ? xf : yf, lane, g_box, fill) || ((s.prewon >> p) & 1);
         int ret = -1;
         if (win) {
             s.done = 1;
@@ -706,10 +779,11 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.cur = p ^ 1;
         return ret;
     };
+    auto ply = [&](int act, int fr, bool check) -> int { return ply_f(act, fr, check, nofill); };
     // env B HexEnv.step (HexSingleGame.py:233-263) on top of ply(); returns reward[0]
-    auto envb_step = [&](int act, bool check) -> int {
+    auto envb_step_f = [&](int act, bool check, auto &fill) -> int {
         const int mover = s.cur;
-        const int w = ply(act, mover, check);
+        const int w = ply_f(act, mover, check, fill);
         s.winner = w;
         int r = 0;
         if (w == 3) {
@@ -720,6 +794,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         }
         return mover == 0 ? r : -r;
     };
+    auto envb_step = [&](int act, bool check) -> int { return envb_step_f(act, check, nofill); };
     // a ply of the in-env opponent: the reply inside step, or the opening after a reset
     // (SelfplayWrapper.py:79-80 / :187-190, HexGame.py:224-230 / :259-265); returns reward[0] (B)
     auto opponent_ply = [&](int oa, bool check) -> int {
@@ -777,7 +852,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                     const int p = B ? (v == -1 ? 0 : (v == 1 ? 1 : -1)) : (v == 0 ? 0 : (v == 1 ? 1 : -1));
                     if (p >= 0) {
                         const int y = c / N, x = c - y * N;
-                        if (L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane, g_box)) s.prewon |= 1 << p;
+                        if (L::place(lds, s, c, x * N + y, p, p ? x : y, p ? y : x, lane, g_box, nofill)) s.prewon |= 1 << p;
                     }
                 }
                 if (opens) s.pend = 2; // the opponent still owes its opening (split step)
@@ -860,6 +935,11 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             // ---- slot 1: the agent's ply (two-sided: the mover's)
             int rew = 0, won = 0, f_done = 0, f_winner = -1;
             bool reply = false; // this lane still owes the opponent's reply
+            // (SPEC: the reply is drawn inside the agent's ply, from the frame the opponent's actions are counted in)
+            constexpr bool spec = SPEC != 0 && MODE == M_ROLLOUT1;
+            typename L::NextDraw reply_draw;
+            reply_draw.f = B ? (s.agent ^ 1) : 1;
+            reply_draw.act = 0;
             // B: the mover's frame.  Drawn before the helper's release barrier: registers only.
             const int act = ext_a ? (live ? a.actions[o] : 0) : L::rng_action(s, B ? s.cur : 0);
             HV_MARK(0); // agent action (rng + k-th empty)
@@ -882,11 +962,11 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                         won = s.done && w == 0;
                     }
                 } else if (B) { // SelfPlayEnv.step (SelfplayWrapper.py:174-199), first half
-                    const int rb = envb_step(act, ext_a);
+                    const int rb = spec ? envb_step_f(act, ext_a, reply_draw) : envb_step(act, ext_a);
                     rew = s.agent == 0 ? rb : -rb;
                     reply = !s.done;
                 } else { // hex-v0 HexEnv.step (HexGame.py:244-295), agent BLACK, first half
-                    s.winner = ply(act, 0, ext_a);
+                    s.winner = spec ? ply_f(act, 0, ext_a, reply_draw) : ply(act, 0, ext_a);
                     if (s.winner == 3) s.done = 1;
                     rew = s.winner == 0 ? 1 : (s.winner == 3 ? -100 : 0);
                     reply = !s.done;
@@ -908,7 +988,13 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
             } else {
                 // ---- slot 2: the opponent's reply
                 if (reply) {
-                    const int oa = ext_o ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
+                    int oa;
+                    if (spec) { // drawn inside the agent's ply; consumed now that the reply is really played
+                        L::commit_draw(s);
+                        oa = reply_draw.act;
+                    } else {
+                        oa = ext_o ? a.opp_actions[o] : L::rng_action(s, B ? s.cur : 1);
+                    }
                     const int rb = opponent_ply(oa, ext_o);
                     rew = B ? (s.agent == 0 ? rb : -rb)
                             : (s.winner == 0 ? 1 : (s.winner == 1 ? -1 : (s.winner == 3 ? -100 : 0)));
@@ -1053,8 +1139,26 @@ template <int N, int ENC, int MODE, int VIEWS> static hipError_t lpb_launch2(con
     // the helper wave pays off where compute dominates (self-play rollout: measured +10 %); the
     // two-sided rollout is store-bound and loses 15 % to the handshake, the others do not care
     constexpr int HELPER = (HV_HELPER && MODE == M_ROLLOUT1) ? 1 : 0;
-    hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
-    return hipGetLastError();
+    if constexpr (MODE == M_ROLLOUT1) {
+        // The self-play rollout exists in two forms with identical results.  Drawing the reply inside the agent's
+        // ply shortens the playing wavefront's step by 7 % (2.61 -> 2.43 us at 11x11 without outputs); that is the
+        // whole gain where the launch is bound by that wavefront: fewer playing wavefronts than SIMDs (7x7 / 32 768:
+        // -7 %, 13x13 / 16 384: -4 %) and short launches (11x11 / 65 536 at 20..60 steps per launch: -3 %).  Long
+        // launches of a full chip run against the store path instead (2.6 us per step = 6.3 TB/s), and there the plain
+        // loop is the steadier one: over six placements of the output buffers 2.62-2.77 us per step against 2.52-2.98
+        // (tools/ab_inproc.py, same process, same buffers).
+        static const int force = [] { // A/B experiments: HEXVEC_LPB_SPEC=0 / 1 forces one form
+            const char *ev = getenv("HEXVEC_LPB_SPEC");
+            return ev ? atoi(ev) : -1;
+        }();
+        const bool spec = force >= 0 ? force != 0 : (blocks < 1024 || a.T <= 64);
+        if (spec) hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 1>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+        else hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 0>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+        return hipGetLastError();
+    } else {
+        hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+        return hipGetLastError();
+    }
 }
 template <int N, int ENC, int MODE> static hipError_t lpb_launch1(const KArgs &a, hipStream_t st)
 {

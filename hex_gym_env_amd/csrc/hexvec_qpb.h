@@ -601,22 +601,39 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                 if (!first_half) {
                     // the opening of a board that ended on the reply, from the picked opponent's cumulative opening
                     // distribution on the empty board (SelfplayWrapper.py:79-80): first cell whose entry exceeds u
-                    if (a.pool_cdf && opp_opens) {
-                        int pol = a.pool_pos ? a.pool_pos[min(max((int)nslot + 1, 0), a.pool_size)] : 0;
-                        pol = min(max(pol, 0), a.pool_npol - 1);
-                        const float *cdf = a.pool_cdf + (size_t)pol * C;
-                        const u32 k = row_key((u32)env, nstep + 1ULL, a.pool_seed_lo, a.pool_seed_hi, 6u);
-                        const float u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                        u32 below = 0; // cells of this lane's share whose entry is <= u
-                        for (int cc = c.l; cc < C; cc += L) below += cdf[cc] <= u ? 1u : 0u;
-                        if (L >= 2) below += dpp0<DPP_QUAD_XOR1>(below);
-                        if (L >= 4) below += dpp0<DPP_QUAD_XOR2>(below);
-                        if (L >= 8) below += dpp0<DPP_HALF_MIRROR>(below);
-                        if (L >= 16) below += dpp0<DPP_ROW_MIRROR>(below);
-                        const bool bad = !(cdf[C - 1] == 1.0f); // not a distribution (a NaN logit): cell 0, counted
-                        if (bad && wr && a.pool_bad) atomicAdd(a.pool_bad, 1ULL);
-                        opening_on_empty(bad ? 0 : (int)min(below, (u32)(C - 1)));
-                        s.pend = 0;
+                    // (wave-cooperative: few boards of a wavefront end in one step, so for each of them ALL lanes test one
+                    // cell of its opponent's table each -- one load and one ballot per 64 cells instead of a scan by the
+                    // board's own lanes)
+                    u64 om = a.pool_cdf ? __ballot(opp_opens && c.l == 0) : 0ull;
+                    if (om) {
+                        int pol = 0;
+                        float u = 0.0f;
+                        if (opp_opens) {
+                            pol = a.pool_pos ? a.pool_pos[min(max((int)nslot + 1, 0), a.pool_size)] : 0;
+                            pol = min(max(pol, 0), a.pool_npol - 1);
+                            const u32 k = row_key((u32)env, nstep + 1ULL, a.pool_seed_lo, a.pool_seed_hi, 6u);
+                            u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                        }
+                        const int nact = __popcll(__ballot(true)); // the live lanes are lanes 0 .. nact-1
+                        int open_act = 0;
+                        while (om) {
+                            const int src = __ffsll((long long)om) - 1; // first lane of the board's group
+                            om &= om - 1;
+                            const float ub = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), src));
+                            const float *cdf = a.pool_cdf + (size_t)__builtin_amdgcn_readlane(pol, src) * C;
+                            int below = 0; // cells whose entry is <= u
+                            for (int c0 = 0; c0 < C; c0 += nact) {
+                                const int cc = c0 + lane;
+                                below += __popcll(__ballot(cc < C && cdf[cc] <= ub));
+                            }
+                            const bool bad = !(cdf[C - 1] == 1.0f); // not a distribution (a NaN logit): cell 0, counted
+                            if (bad && lane == src && a.pool_bad) atomicAdd(a.pool_bad, 1ULL);
+                            if (gbase == src) open_act = bad ? 0 : min(below, C - 1);
+                        }
+                        if (opp_opens) {
+                            opening_on_empty(open_act);
+                            s.pend = 0;
+                        }
                     }
                     if (blk == 0 && lane == 0) { // the step is complete: publish its number for the sampling calls
                         a.pool_ctr[0] = nstep + 1ULL;

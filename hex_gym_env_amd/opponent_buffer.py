@@ -27,6 +27,15 @@ class OpponentBuffer:
         self.evaluating = False
         self.eval_cursor = 0
         self.verbose = verbose
+        # bumped by everything that changes WHICH policies play (replace / append / set_eval / assigning best or members):
+        # what a captured collection step or a packed weights table was built from is named by this number, never by
+        # ids of policy objects that may have been freed and their addresses re-used since
+        self.generation = 0
+
+    def __setattr__(self, name, value):
+        if name in ("members", "best", "prob_best"):
+            object.__setattr__(self, "generation", getattr(self, "generation", 0) + 1)
+        object.__setattr__(self, name, value)
 
     def __len__(self):
         return len(self.members)
@@ -54,6 +63,7 @@ class OpponentBuffer:
     def set_eval(self, flag):
         self.eval_cursor = 0
         self.evaluating = bool(flag)
+        self.generation += 1
         assert len(self.members) == len(self.scores)
 
     def replace(self, index, policy, score):
@@ -61,6 +71,7 @@ class OpponentBuffer:
             print("Previous model scores: ", self.scores)
         self.members[index] = policy
         self.scores[index] = score
+        self.generation += 1
         if self.verbose:
             print("Replaced model from index: ", index)
             print("Model score: ", score)
@@ -74,6 +85,7 @@ class OpponentBuffer:
             self.best, self.best_mean_reward = policy, mean_reward
         self.members.append(policy)
         self.scores = np.append(self.scores, 0.0)
+        self.generation += 1
 
     def save_best(self, path=None):
         self.best.save_model(path or ("models/best_model_" + str(self.best_score)))

@@ -15,6 +15,7 @@ Policies are objects with  choose_actions(obs int8 [B,N,N], legal uint8 [B,N*N])
 RandomLegalPolicy (BaseRandomPolicy, :16-24) and MlpActorPolicy (an SB3 MaskablePPO "MlpPolicy"
 actor, loadable from the reference's shipped checkpoints with weights_only=True).
 """
+import collections
 import io
 import weakref
 import zipfile
@@ -71,7 +72,12 @@ def sample_masked_torch(logits, legal, generator=None, bad_rows=None):
     return idx
 
 
-_SAMPLER_STATE = {}     # (device, id(generator)) -> device int64[2] {draw counter, reserved} of hexvec_sample_masked
+# draw counters of hexvec_sample_masked, one per (device, generator): (device, id(generator)) -> (generator, device
+# int64[2] {draw counter, reserved}).  torch.Generator takes neither attributes nor weak references, so an entry HOLDS its
+# generator: an id can then never be re-used by another generator while the entry exists (a fresh generator that inherits a
+# dead one's counter would repeat or skip draws).  Oldest entries leave when the table is full.
+_SAMPLER_STATE = collections.OrderedDict()
+_SAMPLER_STATE_MAX = 1024
 
 
 def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None, out=None, rng=None):
@@ -120,11 +126,15 @@ def _draw_stream(device, generator, rng):
     """(state, seed, salt, advance) of a sampling call: the caller's counter, or the one named by `generator`"""
     if rng is not None:
         return rng
-    key = (device, id(generator))
-    st = _SAMPLER_STATE.get(key)
-    if st is None:
-        st = _SAMPLER_STATE[key] = torch.zeros(2, dtype=torch.int64, device=device)
-    return st, (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1), 0, 1
+    key = (torch.device(device), id(generator))
+    ent = _SAMPLER_STATE.get(key)
+    if ent is None or ent[0] is not generator:
+        ent = _SAMPLER_STATE[key] = (generator, torch.zeros(2, dtype=torch.int64, device=device))
+        while len(_SAMPLER_STATE) > _SAMPLER_STATE_MAX:
+            _SAMPLER_STATE.popitem(last=False)
+    else:
+        _SAMPLER_STATE.move_to_end(key)
+    return ent[1], (generator.initial_seed() if generator is not None else 0x5EED5EED) & (2 ** 64 - 1), 0, 1
 
 
 def mlp_actions(weights, cells, h1, h2, obs, legal, row_active=None, slot=None, slot_bias=0, policy_of_slot=None,
@@ -602,7 +612,7 @@ class VecSelfPlayEnv:
     def _pool_table(self):
         """the pool as one weights table if every member is an MlpActorPolicy of one shape on this device
         (then an opponent round is ONE policy launch whatever the pool holds), else None"""
-        key = tuple(id(self.buffer.policy(k)) for k in range(-1, len(self.buffer)))
+        key = (id(self.buffer), self.buffer.generation)     # (the buffer outlives the key; ids of its members may not)
         if getattr(self, "_table_key", None) != key:
             by_slot = [self.buffer.policy(k) for k in range(-1, len(self.buffer))]
             self._table = _PoolTable(by_slot, self.device, self.num_envs) if _PoolTable.fits(by_slot, self.device) else None
@@ -722,7 +732,7 @@ class VecSelfPlayEnv:
             return None
         if len(groups) == 1:
             return [groups[0][0]], None
-        key = tuple(id(pol) for pol, _ in groups)
+        key = (id(self.buffer), self.buffer.generation)
         if getattr(self, "_pos_key", None) != key:
             pos = [0] * (len(self.buffer) + 1)
             for g, (_, slots) in enumerate(groups):
@@ -869,8 +879,7 @@ class VecSelfPlayEnv:
         """everything host-side that a captured collection step bakes in: the pool's policy objects and
         their grouping, the evaluation flag, the 80/20 split"""
         b = self.buffer
-        return (id(b.best), tuple(map(id, b.members)), bool(b.evaluating), float(b.prob_best), self._any_white,
-                bool(self.fuse_pool))
+        return (id(b), b.generation, bool(b.evaluating), float(b.prob_best), self._any_white, bool(self.fuse_pool))
 
     def capture_collect_step(self, agent_policy, warmup=3):
         """Capture  actions = agent_policy.choose_actions(obs, legal); step(actions)  as ONE hipGraph

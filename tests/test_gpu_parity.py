@@ -658,11 +658,13 @@ def test_config1_thousand_reference_games_5x5(hx):
 
 @LAYOUTS
 @pytest.mark.parametrize("two", [False, True], ids=["selfplay", "two-sided"])
-def test_config4_all_524288_envs_on_one_gpu_and_shard_identity(hx, lay, two):
-    """BASELINE config 4 (11x11, 524 288 envs = 8 x 65 536): the whole job on ONE GPU -- size-independent
-    properties on every row -- and sharding: rank 7's shard (env_offset = 7E/8) reproduces the last eighth of
-    the monolithic run bit for bit, and its first envs match the oracle started at the same global ids."""
-    n, E, T = 11, 524288, 8
+@pytest.mark.parametrize("n,E", [(11, 524288), (13, 131072)], ids=["config4", "config5"])
+def test_full_job_on_one_gpu_and_shard_identity(hx, lay, two, n, E):
+    """BASELINE config 4 (11x11, 524 288 envs = 8 x 65 536) and config 5's env side (13x13, 131 072 envs = 8 x 16 384):
+    the whole job on ONE GPU -- size-independent properties on every row -- and sharding: rank 7's shard
+    (env_offset = 7E/8) reproduces the last eighth of the monolithic run bit for bit, and its first envs match the
+    oracle started at the same global ids.  (Config 5's policy in the loop: test_baseline_config_sizes_selfplay_with_mlp_policy.)"""
+    T = 8
     kw = dict(encoding="B", two_sided=two, seed=2, rollout_layout=lay == "lpb")
     env = hx.HexVecEnv(n, E, **kw)
     fn = env.rollout_random if two else env.rollout_selfplay
@@ -674,7 +676,7 @@ def test_config4_all_524288_envs_on_one_gpu_and_shard_identity(hx, lay, two):
     if two:     # the recorded action was legal in the recorded position
         assert bool(torch.gather(legal, 2, act.long().unsqueeze(-1)).all())
     stones = (obs != 0).sum(-1)
-    assert int(stones.max()) <= n * n and int(done.sum()) == 0          # no 11x11 game ends within 8 steps
+    assert int(stones.max()) <= n * n and int(done.sum()) == 0          # no 11x11 / 13x13 game ends within 8 steps
     st = _np(env.episode_stats())
     assert st[2] == 0
     sh = hx.HexVecEnv(n, E // 8, env_offset=7 * E // 8, **kw)

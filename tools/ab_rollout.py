@@ -17,6 +17,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     out = {k: torch.empty((T, E) + ((C,) if k in ("obs", "legal") else ()), dtype=dt, device="cuda")
            for k, dt in (("obs", torch.int8), ("legal", torch.uint8), ("actions", torch.int32),
                          ("reward", torch.float32), ("done", torch.uint8))}
+    if os.environ.get("OUT", "1") == "0":       # no outputs: the playing wavefront's own time per step
+        out = {}
     fn = env.rollout_random if two else env.rollout_selfplay
     for _ in range(60):
         fn(T, out)
@@ -34,6 +36,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
                                       env.last_kernel()), flush=True)
     sys.exit(0)
 
-for rnd in range(3):
+for rnd in range(int(os.environ.get("ROUNDS", 3))):
     for so in sys.argv[1:]:
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, HEXVEC_SO=os.path.abspath(so)))

@@ -52,6 +52,12 @@ for rep in range(6):
     for k in sorted(set(wpc.tolist())):
         m = wpc == k
         print("   on a CU with %d workgroups: %4d workgroups, steps phase mean %.0f max %.0f" % (k, m.sum(), steps[m].mean(), steps[m].max()))
+    print("   steps phase by XCC (mean / max): " + "  ".join("%d: %.0f / %.0f" % (x, steps[xcc == x].mean(), steps[xcc == x].max())
+                                                              for x in sorted(set(xcc.tolist()))))
+    cyc = st[:, [0, 1, 2, 4, 5, 6]].astype(np.float64).sum(1)          # s_memtime ticks of the step loop (shader clock)
+    print("   shader clock by XCC (loop cycles / loop time, GHz): " + "  ".join(
+        "%d: %.2f" % (x, (cyc[xcc == x] / (steps[xcc == x] * 10.0)).mean()) for x in sorted(set(xcc.tolist())))
+        + "   cycles per step by XCC: " + "  ".join("%d: %.0f" % (x, cyc[xcc == x].mean() / T) for x in sorted(set(xcc.tolist()))))
     print("   launch: first in to last out %.0f; slowest 5 workgroups: %s" % (
         phf[:, 3].max() - phf[:, 0].min(), [(int(i), int(steps[i]), int(share[i]), int(wpc[i])) for i in np.argsort(-steps)[:5]]))
 d = np.stack(durs)
