@@ -43,7 +43,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_COPY_GBPS = 6290.0
-PROFILE_ROUND = "r02"       # profiles/<round>/bench_pmc_summary.json: the PMC passes of the driver's command
+PROFILE_ROUND = "r03"       # profiles/<round>/bench_pmc_summary.json: the PMC passes of the driver's command
 LEG_WARM_MS = 150.0         # warm-up of every secondary leg on its own kernels
 LEG_REPS = 20
 

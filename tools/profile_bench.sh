@@ -22,3 +22,5 @@ for grp in \
 done
 python3 tools/prof_summary.py "$out" > "$out/summary.txt"
 cat "$out/summary.txt"
+# the raw per-dispatch tables are tens of MB (gpurun copies back at most 64 MiB): keep the summaries only
+rm -rf "$out/trace" "$out"/pmc[0-9]
