@@ -30,7 +30,7 @@ SYMBOLS = [
     "hexvec_rollout_random", "hexvec_rollout_selfplay", "hexvec_get_state", "hexvec_set_state", "hexvec_set_boards",
     "hexvec_episode_stats", "hexvec_agent_colours", "hexvec_state_bytes", "hexvec_export_state",
     "hexvec_import_state", "hexvec_stream_synchronize", "hexvec_set_ticket", "hexvec_sample_masked", "hexvec_pick_opponents",
-    "hexvec_attach_pool",
+    "hexvec_attach_pool", "hexvec_mlp_lds_bytes",
     "hexvec_mlp_weights_floats", "hexvec_mlp_scratch_bytes", "hexvec_mlp_pack", "hexvec_mlp_actions", "hexvec_board_size", "hexvec_num_envs",
     "hexvec_flags", "hexvec_last_kernel", "hexvec_last_error",
 ]
@@ -89,6 +89,8 @@ def lib():
     L.hexvec_attach_pool.argtypes = [vp, vp, vp, C.c_float, i32, u64, vp, vp, vp, i32, vp]
     L.hexvec_mlp_weights_floats.argtypes = [i32, i32, i32]
     L.hexvec_mlp_weights_floats.restype = C.c_size_t
+    L.hexvec_mlp_lds_bytes.argtypes = [i32, i32, i32]
+    L.hexvec_mlp_lds_bytes.restype = C.c_size_t
     L.hexvec_mlp_scratch_bytes.argtypes = [i32, i32]
     L.hexvec_mlp_scratch_bytes.restype = C.c_size_t
     L.hexvec_mlp_pack.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]

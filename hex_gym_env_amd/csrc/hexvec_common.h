@@ -117,6 +117,30 @@ __device__ __forceinline__ u32 put_byte(u32 reg, int idx, u32 val, u32 lane)
 // thread-local text behind hexvec_last_error(), shared by every translation unit (defined in hexvec.hip)
 void set_error(const char *what, const char *detail);
 
+// The entry points that take no handle (hexvec_sample_masked, hexvec_pick_opponents, hexvec_mlp_*) work on the device
+// that OWNS their output buffer, whatever the calling thread's current device is: launches, per-device function
+// attributes and device queries inside the guard go to that device; the caller's current device is restored on return.
+struct PointerDeviceGuard {
+    int prev = -1, dev = -1;
+    bool ok = false;
+    explicit PointerDeviceGuard(const void *device_ptr)
+    {
+        hipPointerAttribute_t at;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (device_ptr && hipPointerGetAttributes(&at, device_ptr) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            dev = at.device;
+            ok = dev == prev || hipSetDevice(dev) == hipSuccess;
+        } else {
+            (void)hipGetLastError(); // (not a device pointer: the error is reported by the caller, not left pending)
+        }
+    }
+    ~PointerDeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 // launchers, one per translation unit (so the kernel families compile in parallel)
 hipError_t wpb_launch(int N, int enc, int mode, const KArgs &a, hipStream_t st);
 hipError_t wpb_get_state(const u32 *planes, const u32 *hot, int E, int N, int enc, signed char *board,

@@ -857,6 +857,11 @@ extern "C" int hexvec_mlp_pack(const float *w1, const float *b1, const float *w2
         hv::set_error("hexvec_mlp_pack", "NULL argument, cells out of range or hidden widths not multiples of 16 in [16, 256]");
         return HEXVEC_E_ARG;
     }
+    hv::PointerDeviceGuard guard(dst);
+    if (!guard.ok) {
+        hv::set_error("hexvec_mlp_pack", "dst is not memory of a visible GPU");
+        return HEXVEC_E_ARG;
+    }
     const size_t n = hexvec_mlp_weights_floats(cells, h1, h2);
     hipLaunchKernelGGL(hv::k_mlp_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2,
                        w3, b3, cells, h1, h2, dst);
@@ -866,6 +871,17 @@ extern "C" int hexvec_mlp_pack(const float *w1, const float *b1, const float *w2
         return HEXVEC_E_HIP;
     }
     return HEXVEC_OK;
+}
+
+extern "C" size_t hexvec_mlp_lds_bytes(int cells, int h1, int h2)
+{
+    if (!mlp_shape_ok(cells, h1, h2)) return 0;
+    if (hv::mlp_on_mfma(h1, h2)) { // the larger of the two MFMA kernels' needs
+        const size_t one = (size_t)hv::MF_WAVES * 2 * ((32 * (size_t)cells + 15) & ~(size_t)15);
+        const size_t two = 2 * ((32 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * (2 * 64 * 32 + 3 * 32);
+        return one > two ? one : two;
+    }
+    return 2 * ((64 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * 64 * (size_t)(h1 + h2) + 4 * 64 * (3 * hv::POL_WAVES + 1);
 }
 
 extern "C" size_t hexvec_mlp_scratch_bytes(int rows, int n_policies)
@@ -896,6 +912,8 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
     if (grouped && (!scratch || scratch_bytes < hexvec_mlp_scratch_bytes(rows, n_policies)))
         return fail("scratch missing or smaller than hexvec_mlp_scratch_bytes()");
     if (rows == 0) return HEXVEC_OK;
+    PointerDeviceGuard guard(actions); // the device that owns the outputs (not the thread's current one)
+    if (!guard.ok) return fail("actions is not memory of a visible GPU");
 
     hipStream_t st = (hipStream_t)stream;
     MlpArgs a;
@@ -936,11 +954,13 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
     size_t lds;
     const void *fn;
     // few tiles: two wavefronts per tile, so that every SIMD holds two wavefronts where it would hold one (or none)
-    static const int simds = []() {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 4 * cus;
-    }();
+    static thread_local int simds_of[16] = {};
+    int &simds = simds_of[guard.dev & 15];
+    if (simds == 0) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, guard.dev);
+        simds = 4 * cus;
+    }
     const bool split = mfma && (long long)2 * tiles * 2 <= (long long)3 * simds && getenv("HEXVEC_MLP_NOSPLIT") == nullptr;
     if (mfma && split) {
         lds = 2 * ((32 * (size_t)cells + 15) & ~(size_t)15) + sizeof(float) * (2 * 64 * 32 + 3 * 32);
@@ -956,9 +976,15 @@ extern "C" int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const
     // (device, kernel) of this thread
     static thread_local size_t lds_allowed[16][3] = {};
     const int which = mfma ? (split ? 2 : 1) : 0;
-    int cur_dev = 0;
-    (void)hipGetDevice(&cur_dev);
-    size_t &allowed = lds_allowed[cur_dev & 15][which];
+    size_t &allowed = lds_allowed[guard.dev & 15][which];
+    static thread_local size_t lds_limit[16] = {}; // what a workgroup may be given on that device at all
+    size_t &limit = lds_limit[guard.dev & 15];
+    if (limit == 0) {
+        int v = 64 * 1024;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, guard.dev); // one workgroup may take a CU's whole LDS
+        limit = (size_t)v;
+    }
+    if (lds > limit) return fail("this network shape needs more LDS per workgroup than the device has (use the torch forward)");
     if (lds > 48 * 1024 && lds > allowed) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {

@@ -138,6 +138,11 @@ extern "C" int hexvec_sample_masked(const float *logits, long long logits_row_st
         return HEXVEC_E_ARG;
     }
     if (rows == 0) return HEXVEC_OK;
+    hv::PointerDeviceGuard guard(actions);
+    if (!guard.ok) {
+        hv::set_error("hexvec_sample_masked", "actions is not memory of a visible GPU");
+        return HEXVEC_E_ARG;
+    }
     const long long threads = (long long)rows * 16;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(hv::k_sample_masked, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, logits_row_stride,
@@ -166,6 +171,11 @@ extern "C" int hexvec_pick_opponents(int64_t *slot, int when, const uint8_t *don
         return HEXVEC_E_ARG;
     }
     if (rows == 0) return HEXVEC_OK;
+    hv::PointerDeviceGuard guard(slot);
+    if (!guard.ok) {
+        hv::set_error("hexvec_pick_opponents", "slot is not memory of a visible GPU");
+        return HEXVEC_E_ARG;
+    }
     hipLaunchKernelGGL(hv::k_pick_opponents, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (long long *)slot, when, done, pending, ended, white, rows, prob_best, pool_size, (hv::u32)seed,
                        (hv::u32)(seed >> 32), salt, state2);

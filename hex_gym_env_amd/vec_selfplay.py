@@ -80,6 +80,19 @@ _SAMPLER_STATE = collections.OrderedDict()
 _SAMPLER_STATE_MAX = 1024
 
 
+def _want(t, name, dtype, numel, device):
+    """a tensor handed to libhexvec as a raw pointer: wrong dtype / size / device / layout must raise here, not turn
+    into an out-of-bounds access on the GPU"""
+    if t is None:
+        return
+    if t.dtype != dtype or t.device != device or not t.is_contiguous() or t.numel() < numel:
+        raise ValueError(f"{name} must be a contiguous {dtype} tensor on {device} with at least {numel} elements, "
+                         f"got {tuple(t.shape)} {t.dtype} on {t.device}")
+
+
+_LDS_PER_WORKGROUP = 160 * 1024     # MI355X (the library refuses what exceeds the device's own figure)
+
+
 def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None, out=None, rng=None):
     """One categorical sample per row from softmax(logits) restricted to legal != 0 (logits None = uniform over
     the legal cells; a [1, C] logits row is shared by all boards), by the Gumbel-max trick argmax(logits + G):
@@ -99,22 +112,32 @@ def sample_masked(logits, legal, generator=None, bad_rows=None, row_active=None,
     from . import _lib
     if not legal.is_cuda:
         raise RuntimeError("sample_masked runs on the GPU only (libhexvec has no CPU path)")
+    if legal.dim() != 2:
+        raise ValueError("legal must be [rows, cells]")
     rows, cols = legal.shape
+    dev = legal.device
     lg = legal if legal.dtype == torch.uint8 and legal.is_contiguous() else legal.to(torch.uint8).contiguous()
     lo, stride = None, 0
     if logits is not None:
-        if logits.shape[0] == 1 or (logits.dim() == 2 and logits.stride(0) == 0):   # one row for every board
+        if logits.dim() != 2 or logits.shape[1] != cols or logits.shape[0] not in (1, rows) or logits.device != dev:
+            raise ValueError(f"logits must be [rows or 1, {cols}] on {dev}, got {tuple(logits.shape)} on {logits.device}")
+        if logits.shape[0] == 1 or logits.stride(0) == 0:   # one row for every board
             lo = logits[:1].float().contiguous()
         else:
             lo = logits if logits.dtype == torch.float32 and logits.is_contiguous() else logits.float().contiguous()
             stride = cols
     ra = None
     if row_active is not None:
+        if row_active.numel() != rows or row_active.device != dev:
+            raise ValueError("row_active must have one entry per row, on the device of legal")
         ra = row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)
         ra = ra.contiguous()
     st, seed, salt, advance = _draw_stream(legal.device, generator, rng)
     if out is None:
         out = torch.empty(rows, dtype=torch.int32, device=legal.device)
+    _want(out, "out", torch.int32, rows, dev)
+    _want(bad_rows, "bad_rows", torch.int64, 1, dev)
+    _want(st, "the draw counter", torch.int64, 2, dev)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     _lib.check(_lib.lib().hexvec_sample_masked(p(lo), stride, p(lg), p(ra), rows, cols, C.c_uint64(seed), salt,
                                                int(bool(advance)), p(st), p(out), p(bad_rows),
@@ -148,7 +171,9 @@ def mlp_actions(weights, cells, h1, h2, obs, legal, row_active=None, slot=None, 
     from . import _lib
     if not legal.is_cuda:
         raise RuntimeError("mlp_actions runs on the GPU only (libhexvec has no CPU path)")
-    rows = legal.shape[0]
+    rows, dev = legal.shape[0], legal.device
+    if obs.device != dev or obs.numel() != rows * cells or legal.dim() != 2:
+        raise ValueError("obs / legal do not describe the same %d-cell boards on one device" % cells)
     ob = obs.reshape(rows, -1)
     ob = ob if ob.dtype == torch.int8 and ob.is_contiguous() else ob.to(torch.int8).contiguous()
     lg = legal if legal.dtype == torch.uint8 and legal.is_contiguous() else legal.to(torch.uint8).contiguous()
@@ -156,7 +181,11 @@ def mlp_actions(weights, cells, h1, h2, obs, legal, row_active=None, slot=None, 
         raise ValueError("obs / legal do not have %d cells per board" % cells)
     ra = None
     if row_active is not None:
+        if row_active.numel() != rows or row_active.device != dev:
+            raise ValueError("row_active must have one entry per row, on the device of legal")
         ra = (row_active if row_active.dtype == torch.uint8 else row_active.to(torch.uint8)).contiguous()
+    if weights.device != dev:
+        raise ValueError("the packed weights must live on the device of the boards")
     weights = weights.view(-1, weights.shape[-1])
     n_pol = weights.shape[0]
     L = _lib.lib()
@@ -164,14 +193,20 @@ def mlp_actions(weights, cells, h1, h2, obs, legal, row_active=None, slot=None, 
         raise ValueError("weights are not float32 [n_policies, hexvec_mlp_weights_floats(cells, h1, h2)]")
     n_slots = 1
     if slot is not None:
-        if slot.dtype != torch.long or not slot.is_contiguous():
-            raise ValueError("slot must be a contiguous int64 tensor")
+        _want(slot, "slot", torch.long, rows, dev)
+        _want(policy_of_slot, "policy_of_slot", torch.int32, 1, dev)
         n_slots = n_pol if policy_of_slot is None else policy_of_slot.numel()
         if n_pol > 1 and scratch is None:
             scratch = torch.empty(L.hexvec_mlp_scratch_bytes(rows, n_pol), dtype=torch.uint8, device=legal.device)
     st, seed, salt, advance = _draw_stream(legal.device, generator, rng)
     if out is None:
         out = torch.empty(rows, dtype=torch.int32, device=legal.device)
+    _want(out, "out", torch.int32, rows, dev)
+    _want(logits_out, "logits_out", torch.float32, rows * cells, dev)
+    _want(bad_rows, "bad_rows", torch.int64, 1, dev)
+    _want(st, "the draw counter", torch.int64, 2, dev)
+    if scratch is not None and (scratch.device != dev or scratch.dtype != torch.uint8 or not scratch.is_contiguous()):
+        raise ValueError("scratch must be a contiguous uint8 tensor on the device of the boards")
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     _lib.check(L.hexvec_mlp_actions(p(ob), p(lg), p(ra), p(slot), slot_bias, p(policy_of_slot), n_slots, rows, cells,
                                     p(weights), n_pol, h1, h2, int(bool(deterministic)), C.c_uint64(seed), salt,
@@ -227,10 +262,20 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         self.generator = generator
         self.n_cells, self.hidden = n_cells, tuple(hidden)
         # the fused libhexvec call serves the SB3-default shape family; anything else keeps the torch spelling
-        self.fusable = len(self.hidden) == 2 and all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
+        self.fusable = len(self.hidden) == 2 and self._shape_fits(n_cells, self.hidden)
         self._packed = self._packed_version = None
         self._compute_device = None     # None: where the parameters live; view_of_sb3() names the env's GPU
         self._owner = None
+
+    @staticmethod
+    def _shape_fits(n_cells, hidden):
+        """can hexvec_mlp_actions serve this network: widths multiples of 16 in [16, 256] AND the kernel's LDS need
+        within what one workgroup gets (256-256 at 16x16 and larger does not fit: the torch forward is used)"""
+        if not all(h % 16 == 0 and 16 <= h <= 256 for h in hidden):
+            return False
+        from . import _lib
+        need = int(_lib.lib().hexvec_mlp_lds_bytes(int(n_cells), int(hidden[0]), int(hidden[1])))
+        return 0 < need <= _LDS_PER_WORKGROUP
 
     @classmethod
     def view_of_sb3(cls, model, device, deterministic=False, generator=None):
@@ -257,7 +302,7 @@ class MlpActorPolicy(torch.nn.Module, _CountsBadRows):
         self.policy_net, self.action_net = pnet, act            # shared modules: live weights
         self.deterministic, self.generator = deterministic, generator
         self.n_cells, self.hidden = int(lins[0].in_features), (int(lins[0].out_features), int(lins[1].out_features))
-        self.fusable = all(h % 16 == 0 and 16 <= h <= 256 for h in self.hidden)
+        self.fusable = self._shape_fits(self.n_cells, self.hidden)
         self._packed = self._packed_version = None
         self._compute_device = torch.device(device)
         self._owner = weakref.ref(model)        # (weak: the view is cached per model, see as_policy)

@@ -309,6 +309,11 @@ int hexvec_attach_pool(hexvec_t *h, int64_t *slot, uint8_t *ended, float prob_be
  * logits_out.  All pointers are device pointers. */
 size_t hexvec_mlp_weights_floats(int cells, int h1, int h2);
 size_t hexvec_mlp_scratch_bytes(int rows, int n_policies);
+/* LDS bytes per workgroup the call needs for this shape (0: shape not served): a caller falls back to its own forward
+ * pass when that exceeds what the GPU gives one workgroup (160 KB on MI355X; hexvec_mlp_actions refuses it otherwise).
+ * The handle-less entry points (hexvec_sample_masked, hexvec_pick_opponents, hexvec_mlp_*) run on the GPU that owns
+ * their output buffer, whatever the calling thread's current device is. */
+size_t hexvec_mlp_lds_bytes(int cells, int h1, int h2);
 int hexvec_mlp_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
                     int cells, int h1, int h2, float *dst, void *stream);
 int hexvec_mlp_actions(const int8_t *obs, const uint8_t *legal, const uint8_t *row_active, const int64_t *slot,

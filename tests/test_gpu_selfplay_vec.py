@@ -1067,3 +1067,40 @@ def test_attach_pool_rejects_other_handles(hx):
     assert L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(1.5), 4, C.c_uint64(1), p(st), None, None, 1, None) == -1
     assert L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(0.8), 4, C.c_uint64(1), p(st), None, None, 1, None) == 0
     assert L.hexvec_attach_pool(env._h, None, None, C.c_float(0.0), 1, C.c_uint64(0), None, None, None, 1, None) == 0
+
+
+def test_raw_pointer_wrappers_validate_their_tensors(hx):
+    """sample_masked / mlp_actions hand raw pointers to the library: a mistyped, misplaced or short tensor must raise
+    here instead of becoming an out-of-bounds access on the GPU; a network whose fused kernel would not fit the LDS
+    (256-256 at 16x16) is served by the torch forward instead of failing"""
+    from hex_gym_env_amd.vec_selfplay import MlpActorPolicy, mlp_actions, sample_masked
+    rows, C = 64, 25
+    legal = torch.ones((rows, C), dtype=torch.uint8, device="cuda")
+    logits = torch.zeros((rows, C), device="cuda")
+    for bad in (dict(logits=torch.zeros((rows, C + 1), device="cuda")), dict(logits=logits.cpu()),
+                dict(out=torch.empty(rows, dtype=torch.int64, device="cuda")),
+                dict(out=torch.empty(rows - 1, dtype=torch.int32, device="cuda")),
+                dict(row_active=torch.ones(rows + 3, dtype=torch.uint8, device="cuda")),
+                dict(bad_rows=torch.zeros((), dtype=torch.int32, device="cuda"))):
+        kw = dict(logits=logits)
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            sample_masked(kw.pop("logits"), legal, **kw)
+    pol = MlpActorPolicy(C).cuda()
+    obs = torch.zeros((rows, 5, 5), dtype=torch.int8, device="cuda")
+    w = pol.packed()
+    for bad in (dict(out=torch.empty(rows - 1, dtype=torch.int32, device="cuda")),
+                dict(slot=torch.zeros(rows - 1, dtype=torch.long, device="cuda")),
+                dict(logits_out=torch.empty((rows, C - 1), device="cuda")),
+                dict(row_active=torch.ones(rows - 1, dtype=torch.uint8, device="cuda"))):
+        with pytest.raises(ValueError):
+            mlp_actions(w, C, 64, 64, obs, legal, **bad)
+    with pytest.raises(ValueError):
+        mlp_actions(w, C, 64, 64, obs[:-1], legal)
+    assert hx._lib.lib().hexvec_mlp_lds_bytes(256, 256, 256) > 160 * 1024
+    big = MlpActorPolicy(256, hidden=(256, 256), deterministic=True).cuda()
+    assert not big.fusable and MlpActorPolicy(121, hidden=(256, 256)).fusable
+    obs16 = torch.zeros((8, 16, 16), dtype=torch.int8, device="cuda")
+    legal16 = torch.ones((8, 256), dtype=torch.uint8, device="cuda")
+    a = big.choose_actions(obs16, legal16)
+    assert torch.equal(a.long(), big.logits(obs16, legal16).argmax(1))
