@@ -440,6 +440,15 @@ def test_bench_json_contract():
     cs = d["collect_step"]                  # BASELINE config 3 with the policy in the loop (secondary entry)
     assert "error" not in cs and cs["us_per_step"] > 0 and cs["degenerate_rows"] == 0
     assert abs(cs["agent_steps_per_s"] - 32768 / (cs["us_per_step"] * 1e-6)) / cs["agent_steps_per_s"] < 1e-9
+    # the timed kernel at the timed geometry against the oracle, after the timed region (exit code 1 on a mismatch)
+    v = d["verified"]
+    assert v["equal"] is True and v["all_ranks_equal"] is True and v["envs"] == 2048 and v["steps"] == 20
+    assert v["kernel"] == r["kernel"] and set(v["rows"]) == {"obs", "legal", "actions", "reward", "done"}
+    # every secondary leg: own warm-up, >= 20 repetitions, median and min / max
+    for leg, key in (("host_stepped", "us_min_max"), ("rollout_w2", "launch_us_min_max"), ("collect_step", "us_min_max"),
+                     ("ppo_update", "us_min_max")):
+        assert d[leg]["reps"] >= 20 and d[leg][key][0] <= d[leg][key][1], leg
+    assert d["ppo_update"]["us_per_minibatch"] > 0 and "error" not in d["ppo_update"]
 
 
 def _bench_under_launcher(nranks):
@@ -471,6 +480,28 @@ def test_bench_under_torch_distributed_run_one_rank():
     max-over-ranks all_reduce run on the device"""
     d = _bench_under_launcher(1)
     assert d["episodes"]["n"] > 0
+
+
+def test_bench_starts_its_own_rank_on_the_gpu_box():
+    """`bench.py --gpus N` without a launcher starts the ranks itself (torch.distributed.run as a child process, decided
+    before anything touches the GPU) and relays rank 0's line; with one GPU: `--gpus 1 --force-launcher`"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-launcher", "--steps", "20",
+                          "--warmup", "5", "--envs", "8192", "--layout", "rollout", "--no-cpu", "--no-host-stepped",
+                          "--no-w2", "--no-collect"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_envs"] == 8192 and d["verified"]["equal"] is True
+    if torch.cuda.device_count() < 2:       # and a job this box cannot hold is refused, not reported under another name
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20"],
+                             capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert out.returncode != 0 and "n_gpus" not in out.stdout
 
 
 def test_bench_two_ranks_over_rccl():
