@@ -1135,3 +1135,48 @@ def test_raw_pointer_wrappers_validate_their_tensors(hx):
     legal16 = torch.ones((8, 256), dtype=torch.uint8, device="cuda")
     a = big.choose_actions(obs16, legal16)
     assert torch.equal(a.long(), big.logits(obs16, legal16).argmax(1))
+
+
+def test_attach_pool_on_a_hex_v0_handle_through_the_c_abi(hx):
+    """hexvec_attach_pool below the Python wrapper, on an encoding-A self-play handle where the opponent opens every
+    episode (FIRST_WHITE): one hexvec_step_agent + one hexvec_step_opponent complete a step (pending all zero), a board
+    that ended shows exactly the opening stone of the policy its NEW slot names (two one-hot opening tables), the slot of
+    a board changes only when its episode ends, and the published counter counts the steps"""
+    import ctypes as C
+    n, E, Cc = 5, 4096, 25
+    env = hx.HexVecEnv(n, E, encoding="A", first_player=1, seed=6)
+    L = hx._lib.lib()
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    slot = torch.full((E,), -1, dtype=torch.long, device="cuda")
+    ended = torch.zeros(E, dtype=torch.uint8, device="cuda")
+    state = torch.zeros(2, dtype=torch.long, device="cuda")
+    bad = torch.zeros((), dtype=torch.long, device="cuda")
+    cdf = torch.zeros((2, Cc), device="cuda")
+    cdf[0, 7:] = 1.0            # policy 0 always opens at cell 7 (of ITS view), policy 1 at cell 18
+    cdf[1, 18:] = 1.0
+    pos = torch.tensor([0, 1, 0, 1], dtype=torch.int32, device="cuda")     # slot -1 -> policy 0, 0 -> 1, 1 -> 0, 2 -> 1
+    assert L.hexvec_attach_pool(env._h, p(slot), p(ended), C.c_float(0.5), 3, C.c_uint64(99), p(state), p(cdf), p(pos), 2, p(bad)) == 0
+    obs, legal = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    seen = torch.zeros(2, dtype=torch.long, device="cuda")
+    for t in range(40):
+        prev_slot = slot.clone()
+        act = torch.multinomial(legal.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        o1, l1, pend = env.step_agent(act)
+        opp = torch.multinomial(l1.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        # boards that ended on the agent's ply already have their new slot; their opening is the caller's to supply
+        # with the replies (the wrapper's opponent round does that): the cell of the policy the slot names
+        owed = pend == 2
+        opp = torch.where(owed, torch.where(pos[(slot + 1).long()] == 0, 7, 18).to(torch.int32), opp)
+        obs, rew, done, legal, win, pend = env.step_opponent(opp)
+        assert int(pend.sum()) == 0 and int(state[0]) == t + 1
+        fresh = done != 0
+        assert bool((slot[~fresh] == prev_slot[~fresh]).all())
+        o = obs.reshape(E, Cc)
+        assert bool(((o[fresh] != 2).sum(1) == 1).all())            # exactly the opening stone (WHITE = 1) on a fresh board
+        # the opponent chose in ITS view (the transposed board): cell c there is cell T(c) here
+        cell = (o[fresh].reshape(-1, n, n).transpose(1, 2).reshape(-1, Cc) == 1).float().argmax(1)
+        want = torch.where(pos[(slot[fresh] + 1).long()] == 0, 7, 18)
+        assert torch.equal(cell, want), t
+        seen += torch.bincount(pos[(slot[fresh] + 1).long()].long(), minlength=2)
+    assert int(seen.min()) > 100 and int(bad) == 0 and set(slot.tolist()) == {-1, 0, 1, 2}
