@@ -537,6 +537,27 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             signed char *tobs_row = a.tobs ? a.tobs + (size_t)e0 * C : nullptr;
             int rew = 0, won = 0;
             bool fin = false; // the env step completed in this call
+            // hexvec_attach_pool: what the launch's tail needs from memory is requested HERE, before the ply, so that the
+            // tail of this latency-bound launch (one wavefront per SIMD at the geometries that use it) waits for no
+            // round trip of its own: the step counter, the slot -> policy table (lane l holds entry l) and, with one
+            // policy, that policy's cumulative opening distribution (lane l holds cells l, l + 64, ...)
+            constexpr int NCV = (C + 63) / 64;
+            unsigned long long nstep = 0;
+            int pos_of_lane = 0;
+            float cdf_of_lane[NCV], cdf_last = 1.0f;
+            const int nact = __popcll(__ballot(true)); // the live lanes are lanes 0 .. nact-1
+            const bool cdf_preloaded = a.pool_slot && a.phase != 1 && a.pool_cdf && a.pool_npol == 1 && nact == 64;
+            if (a.pool_slot) {
+                nstep = a.pool_ctr[a.phase == 1 ? 0 : 1];
+                if (a.phase != 1 && a.pool_cdf) {
+                    if (a.pool_pos) pos_of_lane = a.pool_pos[min(lane, a.pool_size)];
+                    if (cdf_preloaded) {
+#pragma unroll
+                        for (int k = 0; k < NCV; ++k) cdf_of_lane[k] = a.pool_cdf[min(k * 64 + lane, C - 1)];
+                        cdf_last = a.pool_cdf[C - 1];
+                    }
+                }
+            }
             if (a.phase == 1) { // the agent's ply (slot 1)
                 if (s.pend == 0) {
                     const int act = ext_a ? a.actions[o] : QQ::rng_action(s, B ? s.cur : 0, c);
@@ -584,7 +605,6 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                 // behind the agent's launch / (when = 4, salt 4) behind the opponent's.  The step counter comes from
                 // the handle's own two words: each launch reads the one the OTHER phase writes, so no launch reads a
                 // word it writes.
-                const unsigned long long nstep = a.pool_ctr[a.phase == 1 ? 0 : 1];
                 const bool first_half = a.phase == 1;
                 if (first_half && wr) a.pool_ended[o] = dn ? 1 : 0;
                 // a board qualifies at one point at most: ended and the agent moves first on the fresh board
@@ -606,27 +626,39 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                     // board's own lanes)
                     u64 om = a.pool_cdf ? __ballot(opp_opens && c.l == 0) : 0ull;
                     if (om) {
-                        int pol = 0;
                         float u = 0.0f;
                         if (opp_opens) {
-                            pol = a.pool_pos ? a.pool_pos[min(max((int)nslot + 1, 0), a.pool_size)] : 0;
-                            pol = min(max(pol, 0), a.pool_npol - 1);
                             const u32 k = row_key((u32)env, nstep + 1ULL, a.pool_seed_lo, a.pool_seed_hi, 6u);
                             u = ((float)(mix32(k) >> 8) + 0.5f) * (1.0f / 16777216.0f);
                         }
-                        const int nact = __popcll(__ballot(true)); // the live lanes are lanes 0 .. nact-1
+                        const int slot_ix = min(max((int)nslot + 1, 0), a.pool_size); // index into the slot -> policy table
                         int open_act = 0;
                         while (om) {
                             const int src = __ffsll((long long)om) - 1; // first lane of the board's group
                             om &= om - 1;
                             const float ub = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), src));
-                            const float *cdf = a.pool_cdf + (size_t)__builtin_amdgcn_readlane(pol, src) * C;
                             int below = 0; // cells whose entry is <= u
-                            for (int c0 = 0; c0 < C; c0 += nact) {
-                                const int cc = c0 + lane;
-                                below += __popcll(__ballot(cc < C && cdf[cc] <= ub));
+                            bool bad;
+                            if (cdf_preloaded) {
+#pragma unroll
+                                for (int k = 0; k < NCV; ++k)
+                                    below += __popcll(__ballot(k * 64 + lane < C && cdf_of_lane[k] <= ub));
+                                bad = !(cdf_last == 1.0f);
+                            } else {
+                                int pol = 0;
+                                if (a.pool_pos) { // entry slot_ix of the table: from the lane that holds it, or from memory
+                                    const int six = __builtin_amdgcn_readlane(slot_ix, src);
+                                    pol = six < nact ? __builtin_amdgcn_readlane(pos_of_lane, six) : a.pool_pos[six];
+                                }
+                                pol = min(max(pol, 0), a.pool_npol - 1);
+                                const float *cdf = a.pool_cdf + (size_t)pol * C;
+                                for (int c0 = 0; c0 < C; c0 += nact) {
+                                    const int cc = c0 + lane;
+                                    below += __popcll(__ballot(cc < C && cdf[cc] <= ub));
+                                }
+                                bad = !(cdf[C - 1] == 1.0f);
                             }
-                            const bool bad = !(cdf[C - 1] == 1.0f); // not a distribution (a NaN logit): cell 0, counted
+                            // (bad: not a distribution, e.g. a NaN logit: cell 0, counted)
                             if (bad && lane == src && a.pool_bad) atomicAdd(a.pool_bad, 1ULL);
                             if (gbase == src) open_act = bad ? 0 : min(below, C - 1);
                         }
