@@ -132,7 +132,8 @@ static const char *qpb_kname(int mode)
 {
     switch (mode) {
     case M_ROLLOUT2: return "k_qpb<rollout2>";
-    case M_STEP: return "k_qpb<step>";
+    case M_STEP:
+    case M_STEP_RNG: return "k_qpb<step>";
     case M_ROLLOUT1: return "k_qpb<rollout1>";
     case M_SETBOARD: return "k_qpb<set_boards>";
     default: return "k_qpb<reset>";
@@ -278,7 +279,11 @@ extern "C" int hexvec_step(hexvec_t *h, const int32_t *actions, const int32_t *o
     a.done = done;
     a.winner = (signed char *)winner;
     a.tobs = (signed char *)terminal_obs;
-    return hv::run(h, hv::M_STEP, a, stream);
+    // both sides drawn by the library on a self-play handle of the default layout (the random-policy workload): the
+    // same step from the kernel compiled without the external-action / split-phase paths (739 -> ~590 vector
+    // instructions per wavefront at 11x11, and the launch is bound by exactly those)
+    const bool rng_both = !actions && !opp_actions && h->fast_mode && h->qpb && !(h->flags & HEXVEC_F_TWO_SIDED);
+    return hv::run(h, rng_both ? hv::M_STEP_RNG : hv::M_STEP, a, stream);
 }
 
 extern "C" int hexvec_step_agent(hexvec_t *h, const int32_t *actions, int8_t *obs, uint8_t *legal,

@@ -17,7 +17,9 @@ constexpr int PLANE_WORDS = 3 * 64; // per env: L0, L1, F|FT<<4   (768 B)
 constexpr int HOT_WORDS = 8;  // per env: counters touched every step (32 B)
 constexpr int STAT_WORDS = 4; // per env: episode sums (64-bit each), touched at episode end
 
-enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6 };
+// M_STEP_RNG: hexvec_step on a self-play handle with BOTH sides drawn by the library (actions == opp_actions == NULL, the
+// random-policy workload): the whole-step loop compiled without the external-action and split-phase paths (bitboard family)
+enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6, M_STEP_RNG = 7 };
 
 struct KArgs {
     unsigned char *fast; // lane-per-board state (fast handles)

@@ -368,7 +368,8 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     u32 *rblk = reinterpret_cast<u32 *>(a.fast + (size_t)blk * G::BLOCK_BYTES);
     // [E][4] 64-bit episode sums since create (sum_len alone passes 2^31 after hours of rollouts), behind the blocks
     longlong2 *stats = reinterpret_cast<longlong2 *>(a.fast + (size_t)nb * G::BLOCK_BYTES) + (size_t)env * 2;
-    const bool two = (a.flags & HEXVEC_F_TWO_SIDED) != 0;
+    // (the self-play rollout is launched on self-play handles only, the two-sided one on two-sided handles: hexvec.hip)
+    const bool two = (MODE == M_ROLLOUT1 || MODE == M_STEP_RNG) ? false : (MODE == M_ROLLOUT2 ? true : (a.flags & HEXVEC_F_TWO_SIDED) != 0);
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
     const int gbase = lane & ~(L - 1); // first lane of the group
@@ -865,6 +866,7 @@ template <int N, int ENC> static hipError_t qpb_launch_mode(int mode, const KArg
     switch (mode) {
     case M_ROLLOUT2: return qpb_launch1<N, ENC, M_ROLLOUT2>(a, st);
     case M_STEP: return qpb_launch1<N, ENC, M_STEP>(a, st);
+    case M_STEP_RNG: return qpb_launch1<N, ENC, M_STEP_RNG>(a, st);
     case M_ROLLOUT1: return qpb_launch1<N, ENC, M_ROLLOUT1>(a, st);
     case M_RESET: return qpb_launch1<N, ENC, M_RESET>(a, st);
     case M_SETBOARD: return qpb_launch1<N, ENC, M_SETBOARD>(a, st);

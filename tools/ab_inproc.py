@@ -15,7 +15,7 @@ C = N * N
 envs = []
 for so in sys.argv[1:]:
     _lib._lib, _lib.SO_PATH = None, os.path.abspath(so)        # the next HexVecEnv binds this build
-    envs.append((os.path.basename(so), hx.HexVecEnv(N, E, encoding="B", seed=1, rollout_layout=True)))
+    envs.append((os.path.basename(so), hx.HexVecEnv(N, E, encoding="B", seed=1, rollout_layout=os.environ.get("LAYOUT", "rollout") == "rollout")))
 nsets = int(os.environ.get("SETS", 3))
 sets = []
 for i in range(nsets):
