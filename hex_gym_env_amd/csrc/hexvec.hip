@@ -134,6 +134,8 @@ static const char *qpb_kname(int mode)
     case M_ROLLOUT2: return "k_qpb<rollout2>";
     case M_STEP:
     case M_STEP_RNG: return "k_qpb<step>";
+    case M_STEP_AGENT: return "k_qpb<step_agent>";
+    case M_STEP_OPP: return "k_qpb<step_opponent>";
     case M_ROLLOUT1: return "k_qpb<rollout1>";
     case M_SETBOARD: return "k_qpb<set_boards>";
     default: return "k_qpb<reset>";
@@ -303,7 +305,7 @@ extern "C" int hexvec_step_agent(hexvec_t *h, const int32_t *actions, int8_t *ob
     a.winner = (signed char *)winner;
     a.tobs = (signed char *)terminal_obs;
     a.pending = pending;
-    return hv::run(h, hv::M_STEP, a, stream);
+    return hv::run(h, h->qpb ? hv::M_STEP_AGENT : hv::M_STEP, a, stream);
 }
 
 extern "C" int hexvec_step_opponent(hexvec_t *h, const int32_t *opp_actions, int8_t *obs, uint8_t *legal,
@@ -323,7 +325,7 @@ extern "C" int hexvec_step_opponent(hexvec_t *h, const int32_t *opp_actions, int
     a.winner = (signed char *)winner;
     a.tobs = (signed char *)terminal_obs;
     a.pending = pending;
-    return hv::run(h, hv::M_STEP, a, stream);
+    return hv::run(h, h->qpb ? hv::M_STEP_OPP : hv::M_STEP, a, stream);
 }
 
 extern "C" int hexvec_apply_moves(hexvec_t *h, const int32_t *actions, int T, int8_t *ret_out,

@@ -19,7 +19,10 @@ constexpr int STAT_WORDS = 4; // per env: episode sums (64-bit each), touched at
 
 // M_STEP_RNG: hexvec_step on a self-play handle with BOTH sides drawn by the library (actions == opp_actions == NULL, the
 // random-policy workload): the whole-step loop compiled without the external-action and split-phase paths (bitboard family)
-enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6, M_STEP_RNG = 7 };
+// M_STEP_AGENT / M_STEP_OPP: the two halves of the split step (hexvec_step_agent / hexvec_step_opponent) as kernels of their
+// own instead of the `phase` branch of M_STEP (bitboard family; the other families keep M_STEP + phase)
+enum Mode { M_APPLY = 0, M_ROLLOUT2 = 1, M_STEP = 2, M_RESET = 3, M_ROLLOUT1 = 4, M_SETSTATE = 5, M_SETBOARD = 6, M_STEP_RNG = 7,
+            M_STEP_AGENT = 8, M_STEP_OPP = 9 };
 
 struct KArgs {
     unsigned char *fast; // lane-per-board state (fast handles)

@@ -369,7 +369,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
     // [E][4] 64-bit episode sums since create (sum_len alone passes 2^31 after hours of rollouts), behind the blocks
     longlong2 *stats = reinterpret_cast<longlong2 *>(a.fast + (size_t)nb * G::BLOCK_BYTES) + (size_t)env * 2;
     // (the self-play rollout is launched on self-play handles only, the two-sided one on two-sided handles: hexvec.hip)
-    const bool two = (MODE == M_ROLLOUT1 || MODE == M_STEP_RNG) ? false : (MODE == M_ROLLOUT2 ? true : (a.flags & HEXVEC_F_TWO_SIDED) != 0);
+    const bool two = (MODE == M_ROLLOUT1 || MODE == M_STEP_RNG || MODE == M_STEP_AGENT || MODE == M_STEP_OPP) ? false : (MODE == M_ROLLOUT2 ? true : (a.flags & HEXVEC_F_TWO_SIDED) != 0);
     const bool selfplay = !two;
     const int first = (!B && (a.flags & HEXVEC_F_FIRST_WHITE)) ? 1 : 0;
     const int gbase = lane & ~(L - 1); // first lane of the group
@@ -530,8 +530,12 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
         }
         do_emit(a.obs ? a.obs + (size_t)e0 * C : nullptr, a.legal ? a.legal + (size_t)e0 * C : nullptr);
     } else {
-        const bool ext_a = MODE == M_STEP && a.actions, ext_o = MODE == M_STEP && a.opp_actions;
-        if (MODE == M_STEP && a.phase != 0) {
+        constexpr bool STEPPED = MODE == M_STEP || MODE == M_STEP_AGENT || MODE == M_STEP_OPP; // actions may come from the caller
+        const bool ext_a = STEPPED && a.actions, ext_o = STEPPED && a.opp_actions;
+        // the half of the split step this launch is: kernels of their own in this family (hexvec.hip never launches M_STEP
+        // with a.phase != 0 on a bitboard handle)
+        constexpr int phase = MODE == M_STEP_AGENT ? 1 : (MODE == M_STEP_OPP ? 2 : 0);
+        if (phase != 0) {
             // Split step for opponents that are policies on the device: the same slots as below,
             // one launch per slot, with the opponent's actions supplied by the caller.
             const size_t o = (size_t)env;
@@ -547,10 +551,10 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
             int pos_of_lane = 0;
             float cdf_of_lane[NCV], cdf_last = 1.0f;
             const int nact = __popcll(__ballot(true)); // the live lanes are lanes 0 .. nact-1
-            const bool cdf_preloaded = a.pool_slot && a.phase != 1 && a.pool_cdf && a.pool_npol == 1 && nact == 64;
+            const bool cdf_preloaded = a.pool_slot && phase != 1 && a.pool_cdf && a.pool_npol == 1 && nact == 64;
             if (a.pool_slot) {
-                nstep = a.pool_ctr[a.phase == 1 ? 0 : 1];
-                if (a.phase != 1 && a.pool_cdf) {
+                nstep = a.pool_ctr[phase == 1 ? 0 : 1];
+                if (phase != 1 && a.pool_cdf) {
                     if (a.pool_pos) pos_of_lane = a.pool_pos[min(lane, a.pool_size)];
                     if (cdf_preloaded) {
 #pragma unroll
@@ -559,7 +563,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                     }
                 }
             }
-            if (a.phase == 1) { // the agent's ply (slot 1)
+            if (phase == 1) { // the agent's ply (slot 1)
                 if (s.pend == 0) {
                     const int act = ext_a ? a.actions[o] : QQ::rng_action(s, B ? s.cur : 0, c);
                     if (B) {
@@ -606,7 +610,7 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
                 // behind the agent's launch / (when = 4, salt 4) behind the opponent's.  The step counter comes from
                 // the handle's own two words: each launch reads the one the OTHER phase writes, so no launch reads a
                 // word it writes.
-                const bool first_half = a.phase == 1;
+                const bool first_half = phase == 1;
                 if (first_half && wr) a.pool_ended[o] = dn ? 1 : 0;
                 // a board qualifies at one point at most: ended and the agent moves first on the fresh board
                 // (salt 1 after the agent's ply, 5 after the reply), or a fresh board on which the opponent is about
@@ -867,6 +871,8 @@ template <int N, int ENC> static hipError_t qpb_launch_mode(int mode, const KArg
     case M_ROLLOUT2: return qpb_launch1<N, ENC, M_ROLLOUT2>(a, st);
     case M_STEP: return qpb_launch1<N, ENC, M_STEP>(a, st);
     case M_STEP_RNG: return qpb_launch1<N, ENC, M_STEP_RNG>(a, st);
+    case M_STEP_AGENT: return qpb_launch1<N, ENC, M_STEP_AGENT>(a, st);
+    case M_STEP_OPP: return qpb_launch1<N, ENC, M_STEP_OPP>(a, st);
     case M_ROLLOUT1: return qpb_launch1<N, ENC, M_ROLLOUT1>(a, st);
     case M_RESET: return qpb_launch1<N, ENC, M_RESET>(a, st);
     case M_SETBOARD: return qpb_launch1<N, ENC, M_SETBOARD>(a, st);

@@ -22,7 +22,7 @@ def mode_of(name):
     if not m:
         return None
     fam, n, enc, mode = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
-    names = {0: "apply", 1: "rollout2", 2: "step", 3: "reset", 4: "rollout1", 5: "set_state", 6: "set_boards", 7: "step"}
+    names = {0: "apply", 1: "rollout2", 2: "step", 3: "reset", 4: "rollout1", 5: "set_state", 6: "set_boards", 7: "step", 8: "step_agent", 9: "step_opponent"}
     return fam, n, enc, names.get(mode, str(mode))
 
 
