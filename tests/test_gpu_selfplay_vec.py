@@ -1026,14 +1026,15 @@ def test_attached_pool_equals_the_separate_pick_launches(hx, agent, openings):
     assert ea.degenerate_rows() == 0 and eb.degenerate_rows() == 0
 
 
-def test_openings_inside_the_step_follow_each_opponents_opening_distribution(hx):
+@pytest.mark.parametrize("E", [16384, 16384 + 37], ids=["full-wavefronts", "ragged-last-wavefront"])
+def test_openings_inside_the_step_follow_each_opponents_opening_distribution(hx, E):
     """with an opening distribution per pool member (hexvec_attach_pool(open_cdf)), ONE hexvec_step_agent + ONE
     hexvec_step_opponent complete a step: a board that ends on the reply gets its new opponent and that opponent's
     opening inside the same launch (SelfplayWrapper.py:75, :79-80).  All agents WHITE: every fresh board shows exactly
     the opening stone; per pool member the empirical opening frequencies match softmax(logits(empty board)) -- a
     sampled network, an arg-max network (always its best cell) and the uniform random policy."""
     from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy, RandomLegalPolicy
-    n, E, C = 4, 16384, 16
+    n, C = 4, 16
     torch.manual_seed(8)
     sampled, greedy = MlpActorPolicy(C).cuda(), MlpActorPolicy(C, deterministic=True).cuda()
     with torch.no_grad():
@@ -1180,3 +1181,34 @@ def test_attach_pool_on_a_hex_v0_handle_through_the_c_abi(hx):
         assert torch.equal(cell, want), t
         seen += torch.bincount(pos[(slot[fresh] + 1).long()].long(), minlength=2)
     assert int(seen.min()) > 100 and int(bad) == 0 and set(slot.tolist()) == {-1, 0, 1, 2}
+
+
+def test_openings_inside_the_step_single_policy_table_in_registers(hx):
+    """one opening distribution for the whole pool (the reference's usual pool: the same live model in every slot): the
+    launch holds the table in registers (requested before the ply); frequencies match softmax(logits(empty board))"""
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    n, E, C = 5, 8192, 25
+    torch.manual_seed(21)
+    pol = MlpActorPolicy(C).cuda()
+    with torch.no_grad():
+        pol.action_net.bias.mul_(0).add_(torch.linspace(1.0, -2.0, C, device="cuda"))
+    env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=4, base_model=pol, seed=12, agent_player_num=1)
+    env.reset()
+    assert len(env._groups()) == 1
+    counts = torch.zeros(C, dtype=torch.long, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(2)
+    legal = env.vec.legal
+    for t in range(60):
+        act = torch.multinomial(legal.float() + 1e-6, 1, generator=g).view(-1).to(torch.int32)
+        obs, rew, done, legal, win = env.step(act)
+        assert env._attached is not None and env._attached[2] is not None and int(env.vec.pending.sum()) == 0
+        fresh = done != 0
+        o = obs.reshape(E, n, n)[fresh]
+        assert bool(((o != 0).sum((1, 2)) == 1).all())
+        counts += torch.bincount((o.transpose(1, 2).reshape(-1, C) == 1).float().argmax(1), minlength=C)
+    tot = int(counts.sum())
+    assert tot > 20000
+    p = torch.softmax(pol.opening_logits().reshape(-1).double(), 0)
+    f = counts.double() / tot
+    assert float((f - p).abs().max()) < 4.0 * float((p * (1 - p) / tot).sqrt().max()) + 1e-3
+    assert env.degenerate_rows() == 0
