@@ -715,20 +715,6 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.pend = 0;
         L::fresh_regs(s, first);
     } else {
-        // The block image goes HBM -> LDS by LDS-DMA (no VGPR round trip): every 1 KB piece is in flight
-        // before the first one lands.  (A load / ds_write loop waits for each piece in turn: +2 us a launch.)
-        // The tail piece overlaps the one before it, so every instruction runs with all 64 lanes.
-        {
-            constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
-            static_assert(V16 >= 64 && L::LDS_BYTES % 16 == 0, "block image smaller than one piece");
-#pragma unroll
-            for (int k = 0; k < PIECES; ++k) {
-                const int at = (k * 64 + 64 <= V16 ? k * 64 : V16 - 64) * 16;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(sblk + at + lane * 16),
-                    (__attribute__((address_space(3))) void *)(lds + at), 16, 0, 0);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
             s.E0[j] = rblk[j * 64 + lane];
@@ -750,6 +736,22 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         s.sl = r[5 * 64 + lane];
         s.se = r[6 * 64 + lane];
         s.sw = r[7 * 64 + lane];
+        // (the register rows are requested FIRST: loads return in order, so what depends on registers only -- the first
+        // action draw -- runs while the block image below is still in flight)
+        // The block image goes HBM -> LDS by LDS-DMA (no VGPR round trip): every 1 KB piece is in flight
+        // before the first one lands.  (A load / ds_write loop waits for each piece in turn: +2 us a launch.)
+        // The tail piece overlaps the one before it, so every instruction runs with all 64 lanes.
+        {
+            constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
+            static_assert(V16 >= 64 && L::LDS_BYTES % 16 == 0, "block image smaller than one piece");
+#pragma unroll
+            for (int k = 0; k < PIECES; ++k) {
+                const int at = (k * 64 + 64 <= V16 ? k * 64 : V16 - 64) * 16;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(sblk + at + lane * 16),
+                    (__attribute__((address_space(3))) void *)(lds + at), 16, 0, 0);
+            }
+        }
     }
 
     HV_PHASE(blk, 1);
@@ -1030,9 +1032,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
         }
     }
 
-    emit_release();
     HV_PHASE(blk, 2);
-    // state back to HBM
+    // state back to HBM (before the emission's last barrier: from here on both wavefronts only READ the LDS)
     {   // eight 1 KB pieces per trip: the LDS reads of a trip are issued together, then its stores
         constexpr int V16 = L::LDS_BYTES / 16, PIECES = (V16 + 63) / 64;
 #pragma unroll
@@ -1067,6 +1068,7 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     r[5 * 64 + lane] = s.sl;
     r[6 * 64 + lane] = s.se;
     r[7 * 64 + lane] = s.sw;
+    emit_release();
     HV_PHASE(blk, 3);
 }
 
