@@ -537,7 +537,14 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
             if (TWOV) sn.r1[it] = *reinterpret_cast<const uint4 *>(lds + IMG + G::IMG_BYTES + byte0);
         }
     }
-    template <bool OBS, bool LEGAL>
+    // GAP > 0 (the helper wavefront where the store path bounds the launch): s_sleep GAP (64 GAP cycles) after every
+    // 1 KB store instruction.  Sixteen to twenty-five such stores issued back to back by each of 1 024 wavefronts are
+    // what the write path handles worst: saturated with bursts it sustains 5.1-5.3 TB/s on most placements of the output
+    // buffers, with the same pieces ~340 cycles apart 6.0-6.5 TB/s on every placement (tools/micro/store_pattern.hip
+    // shows both levels without any game logic).  The optimum is sharp -- s_sleep 4 does not get there and 6 makes
+    // the helper the bound: 13x13 / 65 536 at 100 steps per launch 4.45 / 4.56 / 3.68 / 4.25 us per step for no gap /
+    // 4 / 5 / 6 (tools/ab_inproc.py, same process, same buffers, every buffer set alike).
+    template <bool OBS, bool LEGAL, int GAP = 0>
     static __device__ __forceinline__ void finish(const Snap &sn, u64 view1, signed char *obs, unsigned char *legal,
                                                   int lane)
     {
@@ -555,16 +562,18 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
                 if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
                     if (OBS && pass == 0) __builtin_nontemporal_store(v4u{o.x, o.y, o.z, o.w}, reinterpret_cast<v4u *>(obs + byte0));
                     if (LEGAL && pass == 1) __builtin_nontemporal_store(v4u{l.x, l.y, l.z, l.w}, reinterpret_cast<v4u *>(legal + byte0));
+                    if (GAP > 0 && ((OBS && pass == 0) || (LEGAL && pass == 1))) __builtin_amdgcn_s_sleep(GAP);
                 }
             }
         }
     }
+    template <int GAP = 0>
     static __device__ __forceinline__ void finish_any(const Snap &sn, u64 view1, signed char *obs,
                                                       unsigned char *legal, int lane)
     {
-        if (obs && legal) finish<true, true>(sn, view1, obs, legal, lane);
-        else if (obs) finish<true, false>(sn, view1, obs, legal, lane);
-        else finish<false, true>(sn, view1, obs, legal, lane);
+        if (obs && legal) finish<true, true, GAP>(sn, view1, obs, legal, lane);
+        else if (obs) finish<true, false, GAP>(sn, view1, obs, legal, lane);
+        else finish<false, true, GAP>(sn, view1, obs, legal, lane);
     }
     // wave-cooperative: obs (+ legal mask) of the block's boards, board d in view bit d of `view1`.
     // All LDS reads of the span are issued first, then merged and stored as whole 1 KiB pieces;
@@ -622,6 +631,11 @@ template <int N, int ENC, int BPW, int VIEWS> struct FastState {
 template <int N, int ENC, int MODE, int BPW, int HELPER, int VIEWS, int SPEC = 0>
 __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 {
+    // The plain form of the self-play rollout runs where the store path is the bound (lpb_launch2): from 12x12 on its
+    // helper wavefront spaces its stores (Lpb::finish).  At 11x11 the spaced helper and the playing wavefront take the
+    // same time (2.70-2.77 us per step on every placement against 2.58-2.98 by placement without the gaps: no gain on
+    // average), below that the playing wavefront is the bound and the gaps only cost (+2 %).
+    constexpr int STORE_GAP = (MODE == M_ROLLOUT1 && SPEC == 0 && N >= 12) ? 5 : 0;
     using L = Lpb<N, ENC, BPW, VIEWS>;
     using G = Geo<N, BPW>;
     using LS = typename L::LS;
@@ -666,7 +680,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 if (a.reward) a.reward[ob + lane] = (float)(int)(signed char)(pk >> 16);
                 if (a.done) a.done[ob + lane] = (unsigned char)((pk >> 8) & 1u);
                 if (a.actions_out) a.actions_out[ob + lane] = (int)(pk & 0xffu);
-                L::finish_any(sn, view, a.obs ? a.obs + ob * C : nullptr, a.legal ? a.legal + ob * C : nullptr, lane);
+                L::template finish_any<STORE_GAP>(
+                    sn, view, a.obs ? a.obs + ob * C : nullptr, a.legal ? a.legal + ob * C : nullptr, lane);
             }
         }
         return;
@@ -1148,12 +1163,14 @@ template <int N, int ENC, int MODE, int VIEWS> static hipError_t lpb_launch2(con
         // -7 %, 13x13 / 16 384: -4 %) and short launches (11x11 / 65 536 at 20..60 steps per launch: -3 %).  Long
         // launches of a full chip run against the store path instead (2.6 us per step = 6.3 TB/s), and there the plain
         // loop is the steadier one: over six placements of the output buffers 2.62-2.77 us per step against 2.52-2.98
-        // (tools/ab_inproc.py, same process, same buffers).
+        // (tools/ab_inproc.py, same process, same buffers).  From 12x12 on a full chip is store-bound at
+        // any launch length (3.5-4.5 us per step against a playing wavefront of 2.7): always the plain form, whose helper
+        // wavefront spaces its stores there (k_lpb, STORE_GAP).
         static const int force = [] { // A/B experiments: HEXVEC_LPB_SPEC=0 / 1 forces one form
             const char *ev = getenv("HEXVEC_LPB_SPEC");
             return ev ? atoi(ev) : -1;
         }();
-        const bool spec = force >= 0 ? force != 0 : (blocks < 1024 || a.T <= 64);
+        const bool spec = force >= 0 ? force != 0 : (blocks < 1024 || (a.T <= 64 && N <= 11));
         if (spec) hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 1>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
         else hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 0>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
         return hipGetLastError();

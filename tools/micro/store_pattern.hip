@@ -22,6 +22,11 @@ template <int PAT> __global__ __launch_bounds__(64) void k(unsigned char *obs, u
     const int span = 64 * C;
     const int nit = (span + 1023) / 1024;
     v4u v = {(u32)lane, (u32)blk, 0x01010101u, 0xFF00FF01u};
+    if (pace < 0) { // staggered start: workgroup b begins b / nb of a step period late, so the chip's writes sweep the row
+        pace = -pace;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)pace * (unsigned)blk / (unsigned)nb;
+        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(2);
+    }
     for (int t = 0; t < T; ++t) {
         if (PAT == 3) {
             unsigned char *b = obs + (size_t)t * row_bytes * 2 + (size_t)blk * chunk * 2;
@@ -40,6 +45,22 @@ template <int PAT> __global__ __launch_bounds__(64) void k(unsigned char *obs, u
                         __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(bl + byte0));
                     }
                 }
+            } else if (PAT == 6) { // the step's pieces spread evenly over `pace` cycles (no burst)
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                int done_pieces = 0;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int it = 0; it < nit; ++it) {
+                        const int byte0 = (it * 64 + lane) * 16;
+                        if (byte0 < span) __builtin_nontemporal_store(v, reinterpret_cast<v4u *>((pass ? bl : bo) + byte0));
+                        ++done_pieces;
+                        const unsigned long long due = (unsigned long long)pace * done_pieces / (2 * nit);
+                        while (__builtin_amdgcn_s_memtime() - t0 < due) __builtin_amdgcn_s_sleep(1);
+                    }
+            } else if (PAT == 5) { // ONE stream: the obs array only (half the bytes per step)
+                for (int it = 0; it < nit; ++it) {
+                    const int byte0 = (it * 64 + lane) * 16;
+                    if (byte0 < span) __builtin_nontemporal_store(v, reinterpret_cast<v4u *>(bo + byte0));
+                }
             } else {
                 for (int pass = 0; pass < 2; ++pass)
                     for (int it = 0; it < nit; ++it) {
@@ -53,7 +74,7 @@ template <int PAT> __global__ __launch_bounds__(64) void k(unsigned char *obs, u
             }
         }
         v.x += 1;
-        if (pace > 0) {
+        if (pace > 0 && PAT != 6) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)pace) __builtin_amdgcn_s_sleep(2);
         }
@@ -104,7 +125,12 @@ static int sweep(int N, int T)
 static int many(int N, int T, int count)
 {
     const int C = N * N, chunk = 64 * C;
-    const size_t row = (size_t)1024 * chunk, arr = row * T + 4096;
+    const size_t row = (size_t)1024 * chunk;
+    size_t arr = row * T + 4096;
+    if (getenv("ROUND_MB")) { // allocation size rounded up to a multiple of ROUND_MB MiB
+        const size_t m = (size_t)atoi(getenv("ROUND_MB")) << 20;
+        arr = (arr + m - 1) / m * m;
+    }
     printf("%dx%d, T %d: %zu MB per array, %d pairs\n", N, N, T, arr >> 20, count);
     for (int i = 0; i < count; ++i) {
         unsigned char *obs, *legal;
@@ -114,15 +140,32 @@ static int many(int N, int T, int count)
         }
         const double a = run<0>(obs, legal, T, C, row, chunk, 0);
         // the arrays crossed: this pair's obs with the previous pair's mask would need both kept; one array alone instead
-        const double b = run<0>(obs, obs, T, C, row, chunk, 0); // both streams into ONE array (same addresses twice)
-        printf("pair %3d obs %p mask %p (mask - obs = %lld MB): %.2f TB/s; both streams into obs: %.2f\n", i, (void *)obs, (void *)legal,
-               (long long)(legal - obs) / (1 << 20), a, b);
+        const double b = 0.5 * run<5>(obs, obs, T, C, row, chunk, 0), c = 0.5 * run<5>(legal, legal, T, C, row, chunk, 0);
+        printf("pair %3d obs %p mask %p (mask - obs = %lld MB): both %.2f TB/s; obs alone %.2f, mask alone %.2f\n", i, (void *)obs, (void *)legal,
+               (long long)(legal - obs) / (1 << 20), a, b, c);
+    }
+    return 0;
+}
+
+// does a staggered start (the writes sweep the row instead of landing all over it) change what the pattern sustains?
+static int stagger(int N, int T)
+{
+    const int C = N * N, chunk = 64 * C;
+    const size_t row = (size_t)1024 * chunk, arr = row * T + 4096;
+    for (int i = 0; i < 3; ++i) {
+        unsigned char *obs, *legal;
+        if (hipMalloc(&obs, arr) != hipSuccess || hipMalloc(&legal, arr) != hipSuccess) return 1;
+        printf("pair %d: unpaced %.2f TB/s; the step's pieces spread over P cycles (one step per P cycles = demand D):\n", i, run<0>(obs, legal, T, C, row, chunk, 0));
+        for (int pace : {4000, 4400, 4800, 5200, 5600, 6000, 6500})
+            printf("   P %d: %.2f TB/s", pace, run<6>(obs, legal, T, C, row, chunk, pace));
+        printf("\n");
     }
     return 0;
 }
 
 int main(int argc, char **argv)
 {
+    if (argc > 3 && atoi(argv[3]) < 0) return stagger(atoi(argv[1]), atoi(argv[2]));
     if (argc > 3) return many(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]));
     if (argc > 2) return sweep(atoi(argv[1]), atoi(argv[2]));
     const int N = argc > 1 ? atoi(argv[1]) : 11, C = N * N, T = 100;
