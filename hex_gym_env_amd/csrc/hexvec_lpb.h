@@ -552,18 +552,28 @@ template <int N, int ENC, int BPW, int VIEWS> struct Lpb {
         // 11x11 / 65 536).  All observation pieces first, then all mask pieces: 1-2 % faster than alternating between
         // the two arrays piece by piece (tools/ab_inproc.py, same process, same buffers, six placements).
         typedef u32 __attribute__((ext_vector_type(4))) v4u;
+        uint4 o[G::NIT]; // the merged observation vectors (two-view boards: the view merge is done once, not per array)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = (it * 64 + lane) * 16;
+            uint4 l;
+            merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], TWOV ? sn.r1[it] : sn.r0[it], o[it], l);
+            if (OBS && ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES)) {
+                __builtin_nontemporal_store(v4u{o[it].x, o[it].y, o[it].z, o[it].w}, reinterpret_cast<v4u *>(obs + byte0));
+                if (GAP > 0) __builtin_amdgcn_s_sleep(GAP);
+            }
+        }
 #pragma unroll
-            for (int it = 0; it < G::NIT; ++it) {
-                const int byte0 = (it * 64 + lane) * 16;
-                uint4 o, l;
-                merge_vec(view1, min(byte0, G::IMG_BYTES - 16), sn.r0[it], TWOV ? sn.r1[it] : sn.r0[it], o, l);
-                if ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES) {
-                    if (OBS && pass == 0) __builtin_nontemporal_store(v4u{o.x, o.y, o.z, o.w}, reinterpret_cast<v4u *>(obs + byte0));
-                    if (LEGAL && pass == 1) __builtin_nontemporal_store(v4u{l.x, l.y, l.z, l.w}, reinterpret_cast<v4u *>(legal + byte0));
-                    if (GAP > 0 && ((OBS && pass == 0) || (LEGAL && pass == 1))) __builtin_amdgcn_s_sleep(GAP);
-                }
+        for (int it = 0; it < G::NIT; ++it) {
+            const int byte0 = (it * 64 + lane) * 16;
+            if (LEGAL && ((it + 1) * 64 * 16 <= G::IMG_BYTES || byte0 < G::IMG_BYTES)) {
+                // the mask of a merged vector: enc B values 0x00 / 0x01 / 0xFF: empty <=> bit 0 clear; enc A values
+                // 0 / 1 / 2: empty <=> bit 1 set (as merge_vec computes it)
+                const uint4 &x = o[it];
+                const v4u l = B ? v4u{~x.x & 0x01010101u, ~x.y & 0x01010101u, ~x.z & 0x01010101u, ~x.w & 0x01010101u}
+                                : v4u{(x.x >> 1) & 0x01010101u, (x.y >> 1) & 0x01010101u, (x.z >> 1) & 0x01010101u, (x.w >> 1) & 0x01010101u};
+                __builtin_nontemporal_store(l, reinterpret_cast<v4u *>(legal + byte0));
+                if (GAP > 0) __builtin_amdgcn_s_sleep(GAP);
             }
         }
     }
@@ -635,7 +645,13 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
     // helper wavefront spaces its stores (Lpb::finish).  At 11x11 the spaced helper and the playing wavefront take the
     // same time (2.70-2.77 us per step on every placement against 2.58-2.98 by placement without the gaps: no gain on
     // average), below that the playing wavefront is the bound and the gaps only cost (+2 %).
-    constexpr int STORE_GAP = (MODE == M_ROLLOUT1 && SPEC == 0 && N >= 12) ? 5 : 0;
+    // The two-sided rollout (SPEC = 1: launched on a full chip) records every ply and is store-bound from 9x9 on.  Its
+    // helper merges two views per vector, so it already spends time between its stores; what is left to add was measured
+    // per board size (us per ply at 65 536 boards, 64 plies per launch, no gap / s_sleep 3 / 4 / 5, same process and
+    // buffers): 9x9 1.78 / 1.73 / 2.04 / 2.36, 10x10 2.13 / 2.46 / 2.82 / 3.19, 11x11 2.97-3.23 / 3.03 / 2.64 / 3.05,
+    // 12x12 3.64 / 3.01 / 3.47 / 3.93, 13x13 3.5-4.1 / 5.39 / 6.52 / 7.66, 14x14 4.65 / 7.56 / 8.95 / 10.3.
+    constexpr int W2_GAP = N == 9 ? 3 : (N == 11 ? 4 : (N == 12 ? 3 : 0));
+    constexpr int STORE_GAP = (MODE == M_ROLLOUT1 && SPEC == 0 && N >= 12) ? 5 : ((MODE == M_ROLLOUT2 && SPEC == 1) ? W2_GAP : 0);
     using L = Lpb<N, ENC, BPW, VIEWS>;
     using G = Geo<N, BPW>;
     using LS = typename L::LS;
@@ -677,9 +693,14 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 __syncthreads(); // the snapshot is in registers: wave 0 may play on
                 // the step's scalar rows too: a store issued by the playing wave would queue behind these
                 // 16-byte stores in the CU's memory pipeline and stall it (measured: 3-5 % of a step)
-                if (a.reward) a.reward[ob + lane] = (float)(int)(signed char)(pk >> 16);
-                if (a.done) a.done[ob + lane] = (unsigned char)((pk >> 8) & 1u);
-                if (a.actions_out) a.actions_out[ob + lane] = (int)(pk & 0xffu);
+                // (the two-sided rollout records a position BEFORE its ply: the scalars that arrive with emission t are
+                // those of ply t - 1; wave 0 writes the last ply's itself)
+                if (MODE != M_ROLLOUT2 || t > 0) {
+                    const size_t os = MODE == M_ROLLOUT2 ? ob - (size_t)a.E : ob;
+                    if (a.reward) a.reward[os + lane] = (float)(int)(signed char)(pk >> 16);
+                    if (a.done) a.done[os + lane] = (unsigned char)((pk >> 8) & 1u);
+                    if (a.actions_out) a.actions_out[os + lane] = (int)(pk & 0xffu);
+                }
                 L::template finish_any<STORE_GAP>(
                     sn, view, a.obs ? a.obs + ob * C : nullptr, a.legal ? a.legal + ob * C : nullptr, lane);
             }
@@ -1029,7 +1050,8 @@ __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
                 handle_done(dn, won, tobs_row);
                 if (dn && opens) opening_on_empty();
             }
-            if (helper_on && MODE == M_ROLLOUT1) { // the helper stores them with the observation rows
+            if (helper_on && (MODE == M_ROLLOUT1 || (MODE == M_ROLLOUT2 && t + 1 < a.T))) {
+                // the helper stores them with the observation rows (two-sided: with the NEXT emission)
                 sh_scal[lane] = ((u32)act & 0xffu) | ((u32)f_done << 8) | (((u32)rew & 0xffu) << 16);
             } else if (live) {
                 if (a.reward) a.reward[o] = (float)rew;
@@ -1153,9 +1175,9 @@ __global__ void k_lpb_stats(const unsigned char *fast, int E, double *out4, unsi
 template <int N, int ENC, int MODE, int VIEWS> static hipError_t lpb_launch2(const KArgs &a, hipStream_t st)
 {
     const int blocks = (a.E + HV_BPW - 1) / HV_BPW;
-    // the helper wave pays off where compute dominates (self-play rollout: measured +10 %); the
-    // two-sided rollout is store-bound and loses 15 % to the handshake, the others do not care
-    constexpr int HELPER = (HV_HELPER && MODE == M_ROLLOUT1) ? 1 : 0;
+    // the helper wave serves the two rollouts (the other modes emit once per launch and do not care): it takes the
+    // stores off the playing wavefront and, where the store path is the bound, paces them (STORE_GAP)
+    constexpr int HELPER = (HV_HELPER && (MODE == M_ROLLOUT1 || MODE == M_ROLLOUT2)) ? 1 : 0;
     if constexpr (MODE == M_ROLLOUT1) {
         // The self-play rollout exists in two forms with identical results.  Drawing the reply inside the agent's
         // ply shortens the playing wavefront's step by 7 % (2.61 -> 2.43 us at 11x11 without outputs); that is the
@@ -1172,6 +1194,12 @@ template <int N, int ENC, int MODE, int VIEWS> static hipError_t lpb_launch2(con
         }();
         const bool spec = force >= 0 ? force != 0 : (blocks < 1024 || (a.T <= 64 && N <= 11));
         if (spec) hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 1>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+        else hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 0>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
+        return hipGetLastError();
+    } else if constexpr (MODE == M_ROLLOUT2) {
+        // the two-sided rollout: a helper wavefront stores the rows as in the self-play one; on a full chip (every ply is
+        // an emission: store-bound from 9x9 on) it spaces its stores (k_lpb, STORE_GAP), below that it does not
+        if (blocks >= 1024 && N >= 9) hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 1>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
         else hipLaunchKernelGGL((lpb::k_lpb<N, ENC, MODE, HV_BPW, HELPER, VIEWS, 0>), dim3(blocks), dim3(64 * (1 + HELPER)), 0, st, a);
         return hipGetLastError();
     } else {
