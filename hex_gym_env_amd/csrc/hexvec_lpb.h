@@ -39,8 +39,9 @@
 //
 // Empty-cell bitboards (one per frame) stay in registers for the uniform
 // random policy (k-th set bit) and the legality test.  Scalars (action,
-// reward, done) are one coalesced store per wave (in the self-play rollout the helper
-// wavefront stores them together with the observation rows).
+// reward, done) are one coalesced store per wave (in the two rollouts the helper
+// wavefront stores them together with the observation rows, and paces its stores where the
+// write path would otherwise collapse under the bursts of 1 024 such wavefronts: Lpb::finish).
 //
 // Scope: handles with auto reset.  Then no ply is ever applied after the end
 // of a game and an illegal action ends the episode at once, so the literal
@@ -636,8 +637,9 @@ template <int N, int ENC, int BPW, int VIEWS> struct FastState {
 // HELPER = 1: 128-thread workgroups.  Wave 0 plays; wave 1 only copies observations: at every emission
 // point wave 0 publishes the view mask and meets wave 1 at a barrier, wave 1 snapshots the images into
 // registers, a second barrier releases wave 0, and wave 1 merges and stores while wave 0 computes on.
-// SPEC = 1 (self-play rollout only): the opponent's reply is drawn inside the agent's ply (Lpb::NextDraw).  Same
-// results; which form is faster depends on what bounds the launch (lpb_launch2).
+// SPEC = 1, self-play rollout: the opponent's reply is drawn inside the agent's ply (Lpb::NextDraw).  Same
+// results; which form is faster depends on what bounds the launch (lpb_launch2).  SPEC = 1, two-sided rollout:
+// a launch on a full chip (the helper paces its stores by the table below).
 template <int N, int ENC, int MODE, int BPW, int HELPER, int VIEWS, int SPEC = 0>
 __global__ __launch_bounds__(64 * (1 + HELPER)) void k_lpb(KArgs a)
 {
