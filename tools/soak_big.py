@@ -42,3 +42,25 @@ for n, E, K in ((11, 4096, 1500), (7, 2048, 1500), (13, 1024, 1200), (5, 2048, 1
             assert np.array_equal(g.episode_stats().cpu().numpy(), o.episode_stats())
             print("ok %2dx%-2d E=%5d layout=%-9s enc %s: %d steps, %d episodes (%.0f s)" % (
                 n, n, E, "rollout" if lay else "bitboard", enc, K, o.episode_stats()[2], time.time() - t0), flush=True)
+
+# two-sided handles: the W2 rollout (helper wavefront, scalars of a ply travelling with the next emission) over many
+# launches of odd lengths, interleaved with host-stepped plies, both layouts, both encodings
+for n, E in ((11, 4096), (9, 2048), (13, 1024), (12, 1024 + 37), (5, 2048)):
+    for lay in (False, True):
+        for enc in ("B", "A"):
+            g = hx.HexVecEnv(n, E, encoding=enc, two_sided=True, seed=77, rollout_layout=lay)
+            o = ho.OracleVec(n, E, seed=77, flags=(ho.F_ENC_B if enc == "B" else 0) | ho.F_TWO_SIDED)
+            o.set_threads(os.cpu_count())
+            for launch in range(14):
+                T = (1, 2, 37, 64, 5, 100, 3, 64, 64, 7, 1, 1, 150, 33)[launch]
+                out = g.rollout_random(T)
+                oobs, olegal, oact, orew, odone = o.rollout(T)
+                for k, ref in (("obs", oobs), ("legal", olegal), ("actions", oact), ("reward", orew), ("done", odone)):
+                    assert np.array_equal(out[k].cpu().numpy(), ref), (n, lay, enc, launch, k)
+                if launch % 4 == 1:
+                    obs, rew, done, legal, win = g.step()
+                    oo, ol, orw, od, ow = o.step()
+                    assert np.array_equal(obs.cpu().numpy().reshape(E, -1), oo) and np.array_equal(done.cpu().numpy(), od), (n, lay, enc, launch)
+            assert np.array_equal(g.episode_stats().cpu().numpy(), o.episode_stats())
+            print("ok two-sided %2dx%-2d E=%5d layout=%-9s enc %s: %d episodes (%.0f s)" % (
+                n, n, E, "rollout" if lay else "bitboard", enc, o.episode_stats()[2], time.time() - t0), flush=True)
