@@ -414,6 +414,19 @@ def main():
                                      "agent_steps_per_s": E3 / (us * 1e-6),
                                      "degenerate_rows": env3.degenerate_rows(agent)}
             del run
+            # the same collection as a PPO collector runs it between two updates: several steps per hipGraph, every step's
+            # rows written straight into the rollout buffer (VecSelfPlayEnv.capture_collect): no inter-graph gap and no
+            # host call per step
+            NS = 8
+            runn = env3.capture_collect(agent, NS)
+            leg = timed_leg(runn, inner=8)
+            extra["collect_rollout"] = {"workload": f"the collect_step workload, {NS} steps per hipGraph, rows written "
+                                                    f"straight into a [{NS}, E, ...] rollout buffer",
+                                        "steps_per_graph": NS, "us_per_step": leg["us_median"] / NS,
+                                        "us_min_max": [leg["us_min"] / NS, leg["us_max"] / NS], "reps": leg["reps"],
+                                        "agent_steps_per_s": E3 * NS / (leg["us_median"] * 1e-6),
+                                        "degenerate_rows": env3.degenerate_rows(agent)}
+            del runn
             # the PPO update on what such steps collect (reported apart from the env metric):
             # plain torch fp32, SB3's default MlpPolicy shape (separate 64-64 tanh actor and critic), clipped
             # surrogate + value + entropy loss with the legal mask, Adam, one minibatch of one collected step

@@ -165,31 +165,57 @@ class HexVecEnv:
             _lib.check(rc)
         return self.obs, self.reward, self.done, self.legal, self.winner
 
-    def step_agent(self, actions=None, terminal_obs=None):
+    def _outs(self, out):
+        """the five per-board output rows of a split-step call: the env's own buffers, or the caller's (`out`: any of
+        obs int8 [E, N, N] / legal uint8 [E, N*N] / reward float32 [E] / done uint8 [E] / winner int8 [E]; e.g. row t of a
+        rollout buffer, so that a collected step needs no copy).  -> (tensors, pointers)"""
+        if not out:
+            return (self.obs, self.legal, self.reward, self.done, self.winner), (self._po, self._pl, self._pr, self._pd, self._pw)
+        E, Cc = self.num_envs, self.cells
+        want = (("obs", torch.int8, E * Cc, self.obs), ("legal", torch.uint8, E * Cc, self.legal),
+                ("reward", torch.float32, E, self.reward), ("done", torch.uint8, E, self.done),
+                ("winner", torch.int8, E, self.winner))
+        unknown = set(out) - {k for k, _, _, _ in want}
+        if unknown:
+            raise KeyError(f"unknown step output(s) {sorted(unknown)}")
+        ts = []
+        for k, dt, n, own in want:
+            t = out.get(k)
+            if t is None:
+                t = own
+            elif t.dtype != dt or t.device != self.device or not t.is_contiguous() or t.numel() != n:
+                raise ValueError(f"step output {k!r} must be a contiguous {dt} tensor of {n} elements on {self.device}, "
+                                 f"got {tuple(t.shape)} {t.dtype} on {t.device}")
+            ts.append(t)
+        return tuple(ts), tuple(_p(t) for t in ts)
+
+    def step_agent(self, actions=None, terminal_obs=None, out=None):
         """Split step, first half: the agent's ply only -> (obs, legal, pending).
 
         Boards with pending == 1 show the OPPONENT's view; feed them to the opponent policy and
         call step_opponent() until pending is all zero (a second call plays the openings of boards
         that were reset with the opponent to move first).  reward / done / winner are complete
-        after the last call."""
+        after the last call.  out: see _outs()."""
         a = self._i32(actions, (self.num_envs,))
         self._tobs(terminal_obs)
-        rc = self._L.hexvec_step_agent(self._h, _p(a), self._po, self._pl, self._pr, self._pd, self._pw,
+        (obs, legal, _, _, _), (po, pl, pr, pd, pw) = self._outs(out)
+        rc = self._L.hexvec_step_agent(self._h, _p(a), po, pl, pr, pd, pw,
                                        _p(terminal_obs), self._pp, C.c_void_p(_raw_stream(self._dev_index)))
         if rc:
             _lib.check(rc)
-        return self.obs, self.legal, self.pending
+        return obs, legal, self.pending
 
-    def step_opponent(self, opp_actions=None, terminal_obs=None):
+    def step_opponent(self, opp_actions=None, terminal_obs=None, out=None):
         """Split step, second half: the opponent's ply on every pending board
-        -> (obs, reward, done, legal, winner, pending)."""
+        -> (obs, reward, done, legal, winner, pending).  out: see _outs()."""
         o = self._i32(opp_actions, (self.num_envs,))
         self._tobs(terminal_obs)
-        rc = self._L.hexvec_step_opponent(self._h, _p(o), self._po, self._pl, self._pr, self._pd, self._pw,
+        (obs, legal, reward, done, winner), (po, pl, pr, pd, pw) = self._outs(out)
+        rc = self._L.hexvec_step_opponent(self._h, _p(o), po, pl, pr, pd, pw,
                                           _p(terminal_obs), self._pp, C.c_void_p(_raw_stream(self._dev_index)))
         if rc:
             _lib.check(rc)
-        return self.obs, self.reward, self.done, self.legal, self.winner, self.pending
+        return obs, reward, done, legal, winner, self.pending
 
     def apply_moves(self, actions):
         """Literal plies (no reset) from actions [T,E] -> ret, done, r_black, legal, obs (after each ply)."""

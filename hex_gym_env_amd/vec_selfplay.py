@@ -861,26 +861,35 @@ class VecSelfPlayEnv:
         self._opening_actions()
         return self.vec.reset(opp_actions=self._opp)
 
-    def step(self, actions):
+    def step(self, actions, out=None):
         """actions int [E] (agent's view) -> obs, reward, done, legal, winner.
 
         Finished boards are reset (with a fresh random position if sample_board); their opponent is
         re-drawn before it opens (if it opens).  No host synchronisation: the number of opponent
-        rounds is fixed (replies, then openings if any agent plays WHITE)."""
+        rounds is fixed (replies, then openings if any agent plays WHITE).
+        out (optional, training mode with the pool attached to the handle only): the caller's rows for this step's
+        results -- any of obs / legal (the NEXT observation and mask) / reward / done / winner, e.g. row t of a rollout
+        buffer -- instead of the env's own buffers (HexVecEnv._outs)."""
         attached, openings_inside = self._attach_pool()
+        if out and not (attached and (openings_inside or not self._any_white)):
+            raise NotImplementedError("step(out=...) needs the training-mode step with the pool attached to the handle "
+                                      "(not evaluation mode, sample_board or a pool member without an opening distribution)")
         if self.buffer.evaluating or self.sample_board:
             return self._step_general(actions)
         if attached:
             # two env launches and one policy launch: the slot choice of every board that starts a new episode, the
             # step counter and (openings_inside) the openings of the boards that ended on the reply ride in the tails
             # of hexvec_step_agent / hexvec_step_opponent -- same boards and same draws as the launches below
-            obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
+            # (with `out`: the agent's launch shows the opponents their boards in the env's own buffers -- scratch --
+            # and only the step's scalar rows go to the caller; the opponent's launch writes the caller's next rows)
+            scal = {k: v for k, v in out.items() if k in ("reward", "done", "winner")} if out else None
+            obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs, out=scal)
             self._opponent_actions(obs, legal, pending, rng=self._rng(3))   # replies (+ openings of boards that just ended)
-            self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+            res = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs, out=out)
             if self._any_white and not openings_inside:     # a pool member without a tabulated opening distribution
                 self._opening_actions(rng=self._rng(6), pending=self.vec.pending)
-                self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
-            return self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner
+                res = self.vec.step_opponent(self._opp, terminal_obs=self.terminal_obs)
+            return res[0], res[1], res[2], res[3], res[4]
         # the same step with every slot update as a launch of its own, the boards that owe no ply are skipped
         # inside the sampler, nothing else is computed on the host side of the ABI
         obs, legal, pending = self.vec.step_agent(actions, terminal_obs=self.terminal_obs)
@@ -1002,6 +1011,89 @@ class VecSelfPlayEnv:
             holder["graph"].replay()
             return (self.vec.obs, self.vec.reward, self.vec.done, self.vec.legal, self.vec.winner,
                     holder["actions"])
+
+        run.captures = 1
+        return run
+
+    def capture_collect(self, agent_policy, n_steps, warmup=2):
+        """n_steps collection steps as ONE hipGraph, every step's rows written straight into a rollout buffer (no copy per
+        step, one host call per n_steps): what a PPO collector does between two updates (SB3's collect_rollouts with
+        n_steps; the reference's scripts: scripts/experiments/*.py:38-47).  Returns run() -> buf, the static buffers
+          obs int8 [n, E, N, N], legal uint8 [n, E, N*N]   what the agent saw / could play at step t
+          actions int32 [n, E], reward float32 [n, E], done uint8 [n, E], winner int8 [n, E]   of step t
+        (overwritten by every run(); the observation after the last step is the env's own vec.obs / vec.legal, where the
+        next run() starts).  Same launches, same draws as n_steps replays of capture_collect_step(): tested equal.
+        Training mode with the pool attached to the handle only (step(out=...)); pool changes capture again."""
+        n, E, N, C = int(n_steps), self.num_envs, self.board_size, self.board_size ** 2
+        dev = self.device
+        buf = dict(obs=torch.empty((n, E, N, N), dtype=torch.int8, device=dev),
+                   legal=torch.empty((n, E, C), dtype=torch.uint8, device=dev),
+                   actions=torch.empty((n, E), dtype=torch.int32, device=dev),
+                   reward=torch.empty((n, E), dtype=torch.float32, device=dev),
+                   done=torch.empty((n, E), dtype=torch.uint8, device=dev),
+                   winner=torch.empty((n, E), dtype=torch.int8, device=dev))
+        holder = {"captures": 0}
+
+        def body():
+            buf["obs"][0].copy_(self.vec.obs)
+            buf["legal"][0].copy_(self.vec.legal)
+            for t in range(n):
+                if getattr(agent_policy, "takes_row_active", False):
+                    agent_policy.choose_actions(buf["obs"][t], buf["legal"][t], out=buf["actions"][t], rng=self._rng(7))
+                else:
+                    buf["actions"][t].copy_(agent_policy.choose_actions(buf["obs"][t], buf["legal"][t]))
+                rows = dict(reward=buf["reward"][t], done=buf["done"][t], winner=buf["winner"][t])
+                if t + 1 < n:       # the next observation goes where the next step reads it
+                    rows.update(obs=buf["obs"][t + 1], legal=buf["legal"][t + 1])
+                self.step(buf["actions"][t], out=rows)
+
+        def capture():
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    body()
+                torch.cuda.synchronize(dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            holder["graph"], holder["version"] = graph, self._pool_version()
+            holder["captures"] += 1
+            holder["policies"] = None
+
+        capture()
+
+        def sync_weights():
+            uniq = holder.get("policies")
+            if uniq is None:
+                seen, uniq = set(), []
+                for pol in [agent_policy] + [self.buffer.policy(k) for k in range(-1, len(self.buffer))]:
+                    if id(pol) not in seen and hasattr(pol, "weights_version"):
+                        seen.add(id(pol))
+                        uniq.append(pol)
+                holder["policies"] = uniq
+            vers = [pol.weights_version() for pol in uniq]
+            if vers == holder.get("weights"):
+                return
+            tab = self._pool_table()
+            if tab is not None:
+                tab.sync()
+            for pol in uniq:
+                if hasattr(pol, "sync_weights"):
+                    pol.sync_weights()
+            op = self._opening_policies() if self._attached is not None else None
+            if op is not None:
+                self._refresh_open_cdf(op[0])
+            holder["weights"] = vers
+
+        def run():
+            if holder["version"] != self._pool_version():
+                capture()
+            sync_weights()
+            run.captures = holder["captures"]
+            holder["graph"].replay()
+            return buf
 
         run.captures = 1
         return run

@@ -445,8 +445,10 @@ def test_bench_json_contract():
     assert v["equal"] is True and v["all_ranks_equal"] is True and v["envs"] == 2048 and v["steps"] == 20
     assert v["kernel"] == r["kernel"] and set(v["rows"]) == {"obs", "legal", "actions", "reward", "done"}
     # every secondary leg: own warm-up, >= 20 repetitions, median and min / max
+    cr = d["collect_rollout"]               # the same collection, 8 steps per graph, rows straight into the rollout buffer
+    assert cr["steps_per_graph"] == 8 and 0 < cr["us_per_step"] <= cs["us_per_step"] * 1.05 and cr["degenerate_rows"] == 0
     for leg, key in (("host_stepped", "us_min_max"), ("rollout_w2", "launch_us_min_max"), ("collect_step", "us_min_max"),
-                     ("ppo_update", "us_min_max")):
+                     ("collect_rollout", "us_min_max"), ("ppo_update", "us_min_max")):
         assert d[leg]["reps"] >= 20 and d[leg][key][0] <= d[leg][key][1], leg
     assert d["ppo_update"]["us_per_minibatch"] > 0 and "error" not in d["ppo_update"]
 
@@ -1212,3 +1214,53 @@ def test_openings_inside_the_step_single_policy_table_in_registers(hx):
     f = counts.double() / tot
     assert float((f - p).abs().max()) < 4.0 * float((p * (1 - p) / tot).sqrt().max()) + 1e-3
     assert env.degenerate_rows() == 0
+
+
+def test_capture_collect_n_steps_equals_n_single_step_replays(hx):
+    """capture_collect(agent, n): n collection steps per hipGraph, every step's rows written straight into the rollout
+    buffer (step(out=...): the split step's launches write the caller's rows).  Same launches and same draws as n
+    replays of capture_collect_step(): from one common state, 8 single-step replays == 2 replays of a 4-step graph, row
+    for row (what the agent saw, what it played, reward, done, winner), and the envs end in the same state"""
+    import copy
+    from hex_gym_env_amd.vec_selfplay import VecSelfPlayEnv, MlpActorPolicy
+    n, E, K = 5, 4096, 4
+    torch.manual_seed(5)
+    agent, opp, opp2 = (MlpActorPolicy(n * n).cuda() for _ in range(3))
+
+    def make():
+        env = VecSelfPlayEnv(board_size=n, num_envs=E, buffer_size=5, base_model=opp, seed=31)
+        env.set_opponent_model(1, opp2, 0.0)      # two networks in the pool: the table path with per-slot openings
+        env.reset()
+        return env
+
+    ea, eb = make(), make()
+    ag_a, ag_b = agent, copy.deepcopy(agent)
+    run1 = ea.capture_collect_step(ag_a)
+    runk = eb.capture_collect(ag_b, K)
+    # one common state for both: env blob (boards, RNG counters, the handle's step counters), slots, the draw counter,
+    # the current observation
+    eb.vec.load_state_dict(ea.vec.state_dict())
+    eb.slot.copy_(ea.slot)
+    eb._pick_state.copy_(ea._pick_state)
+    eb.vec.obs.copy_(ea.vec.obs)
+    eb.vec.legal.copy_(ea.vec.legal)
+    rows = []
+    for t in range(2 * K):
+        seen_obs, seen_legal = ea.vec.obs.clone(), ea.vec.legal.clone()
+        obs, rew, done, legal, win, act = run1()
+        rows.append((seen_obs, seen_legal, act.clone(), rew.clone(), done.clone(), win.clone()))
+    for rep in range(2):
+        buf = runk()
+        for t in range(K):
+            so, sl, a, r, d, w = rows[rep * K + t]
+            assert torch.equal(buf["obs"][t], so) and torch.equal(buf["legal"][t], sl), (rep, t)
+            assert torch.equal(buf["actions"][t], a.to(torch.int32)), (rep, t)
+            assert torch.equal(buf["reward"][t], r) and torch.equal(buf["done"][t], d) and torch.equal(buf["winner"][t], w), (rep, t)
+    assert torch.equal(ea.vec.obs, eb.vec.obs) and torch.equal(ea.vec.legal, eb.vec.legal)
+    assert torch.equal(ea.slot, eb.slot) and torch.equal(ea._pick_state, eb._pick_state)
+    assert torch.equal(ea.vec.state_dict()["blob"], eb.vec.state_dict()["blob"])
+    assert int(sum(r[4].sum() for r in rows)) > E // 4 and runk.captures == 1
+    assert ea.degenerate_rows(ag_a) == 0 and eb.degenerate_rows(ag_b) == 0
+    with pytest.raises(NotImplementedError):            # evaluation mode keeps the general step: no caller rows there
+        eb.set_eval(True)
+        eb.step(torch.zeros(E, dtype=torch.int32, device="cuda"), out=dict(reward=torch.empty(E, device="cuda")))
