@@ -13,9 +13,10 @@ per step) is reported beside it.
 Timing: a fixed internal warm-up of rollout launches (>= 150 ms, the chip needs
 tens of ms of load to settle its clock; reported as warmup_internal_ms) precedes the
 --warmup steps.  The K-step region is then repeated `timed_reps` times back to
-back inside ONE barrier + synchronize bracket; every repetition is timed with
-HIP events on the launch stream.  ms_per_step is the MEDIAN repetition (max
-over ranks) / K and `value` follows from it; wall_ms_per_step (bracket wall
+back inside ONE barrier + synchronize bracket, timed with HIP events on the launch
+stream: one event per group of `reps_per_event` repetitions (~1 ms of launches; an
+event between every two launches would add its own ~3 us barrier packet to each).
+ms_per_step is the MEDIAN group (max over ranks) / repetitions / K and `value` follows from it; wall_ms_per_step (bracket wall
 time / all steps) is printed beside it as the cross-check.  Every secondary leg
 (host_stepped, rollout_w2, collect_step, ppo_update) is measured the same way: >= 150 ms of
 warm-up on that leg's own kernels, >= 20 repetitions, median / min / max reported.
@@ -186,7 +187,9 @@ def main():
     ap.add_argument("--layout", choices=["auto", "rollout", "bitboard"], default="auto",
                     help="state layout of the rollout handles (include/hexvec.h HEXVEC_F_ROLLOUT_LAYOUT); "
                          "auto = by the number of wavefronts the geometry gives (HexVecEnv rollout_layout='auto')")
-    ap.add_argument("--reps", type=int, default=0, help="timed repetitions of the --steps region (0 = auto, >= 20)")
+    ap.add_argument("--reps", type=int, default=0, help="timed event groups of the --steps region (0 = auto, >= 20)")
+    ap.add_argument("--event-group", type=int, default=0,
+                    help="repetitions between two HIP events of the timed region (0 = auto: ~1 ms of launches)")
     ap.add_argument("--warmup-internal-ms", type=float, default=150.0)
     ap.add_argument("--force-launcher", action="store_true",
                     help="start the ranks through torch.distributed.run even for --gpus 1 (tests the self-launch path)")
@@ -294,19 +297,27 @@ def main():
     launches_per_rep = run_steps(args.steps)
     e1.record()
     torch.cuda.synchronize(dev)
-    reps = args.reps or int(min(2000, max(20, 60.0 / max(e0.elapsed_time(e1), 1e-3))))
-    reps = int(hxdist.max_over_ranks(reps, dev))
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    probe_ms = max(e0.elapsed_time(e1), 1e-3)
+    # An event between two launches costs the stream ~3 us (a barrier packet of its own: 61.6 us launch to launch against
+    # 58.2 us without, at 20 steps per launch) -- the instrument, not the workload.  One event per GROUP of repetitions
+    # that lasts >= ~1 ms keeps it below 0.5 %; >= 20 groups and >= ~60 ms of timed work.
+    group = args.event_group or int(min(64, max(1, round(1.0 / probe_ms))))
+    group = int(hxdist.max_over_ranks(group, dev))
+    groups = args.reps or int(min(2000, max(20, 60.0 / (group * probe_ms))))
+    groups = int(hxdist.max_over_ranks(groups, dev))
+    reps = groups * group
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(groups + 1)]
     fence()
     t0 = time.perf_counter()
     evs[0].record()         # libhexvec launches on torch's current stream, as do these events
-    for r in range(reps):
-        run_steps(args.steps)
-        evs[r + 1].record()
+    for g in range(groups):
+        for _ in range(group):
+            run_steps(args.steps)
+        evs[g + 1].record()
     fence()
     wall = time.perf_counter() - t0
-    rep_ms = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(reps))
-    med_ms = rep_ms[len(rep_ms) // 2] if reps % 2 else 0.5 * (rep_ms[reps // 2 - 1] + rep_ms[reps // 2])
+    rep_ms = sorted(evs[g].elapsed_time(evs[g + 1]) / group for g in range(groups))
+    med_ms = rep_ms[groups // 2] if groups % 2 else 0.5 * (rep_ms[groups // 2 - 1] + rep_ms[groups // 2])
     med_ms = hxdist.max_over_ranks(med_ms, dev)
     wall = hxdist.max_over_ranks(wall, dev)
     ms_per_step = med_ms / args.steps
@@ -317,7 +328,7 @@ def main():
     launches = launches_per_rep
     # roofline: the AVERAGE launch duration over the timed region (HIP events), as the contract asks;
     # ms_per_step / value use the median repetition
-    mean_ms = hxdist.max_over_ranks(sum(rep_ms) / reps, dev)
+    mean_ms = hxdist.max_over_ranks(sum(rep_ms) / groups, dev)
     avg_launch_s = mean_ms * 1e-3 / launches
     steps_per_launch = args.steps / launches
     achieved = E * steps_per_launch * bytes_per_step / avg_launch_s / 1e9
@@ -465,7 +476,7 @@ def main():
             "metric": "env-steps/sec (random policy, 11x11)" if N == 11
                       else f"env-steps/sec (random policy, {N}x{N})",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "timed_reps": reps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "timed_reps": reps, "reps_per_event": group,
             "warmup_internal_ms": warm_ms, "wall_ms_per_step": 1e3 * wall / (reps * args.steps),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
