@@ -349,7 +349,7 @@ __device__ __forceinline__ u32 pack_flags(int cur, int done, int agent, int winn
            ((u32)prewon << 9) | ((u32)n_empty << 12);
 }
 
-template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(KArgs a)
+template <int N, int ENC, int MODE> __global__ __launch_bounds__(256) void k_qpb(KArgs a)
 {
     using QQ = Q<N, ENC>;
     using G = Geo<N>;
@@ -359,8 +359,13 @@ template <int N, int ENC, int MODE> __global__ __launch_bounds__(64) void k_qpb(
 
     const int lane = (int)threadIdx.x & 63;
     const typename QQ::LC c = QQ::lane_consts(lane);
-    const int nb = (int)gridDim.x, bi = (int)blockIdx.x;
-    const int blk = (nb & 7) == 0 ? (bi & 7) * (nb >> 3) + (bi >> 3) : bi; // contiguous env ranges per XCD
+    // a workgroup is 1..4 independent wavefronts (nothing is shared between them: fewer, larger workgroups only make
+    // the dispatch of a launch and its retirement shorter); workgroups go round-robin over the XCDs
+    const int nb = (a.E + BPW - 1) / BPW; // wavefronts of the launch = state blocks of the handle
+    const int wpg = (int)blockDim.x >> 6, nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int wgr = (nwg & 7) == 0 ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg; // contiguous env ranges per XCD
+    const int blk = wgr * wpg + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (blk >= nb) return;
     const int brow = lane / L;                                             // the lane's board within the wavefront
     const int e0 = blk * BPW;
     const int env = e0 + brow;
@@ -862,7 +867,13 @@ extern "C" int hexvec_debug_qphases(unsigned long long *host_dst, int nblocks)
 template <int N, int ENC, int MODE> static hipError_t qpb_launch1(const KArgs &a, hipStream_t st)
 {
     const int blocks = (a.E + qpb::Geo<N>::BPW - 1) / qpb::Geo<N>::BPW;
-    hipLaunchKernelGGL((qpb::k_qpb<N, ENC, MODE>), dim3(blocks), dim3(64), 0, st, a);
+    // From one wavefront per SIMD of the chip on, four wavefronts per workgroup: a quarter of the workgroups to
+    // dispatch and retire (11x11 / 65 536 host-stepped: 9.63 -> 9.53 us per launch; the config-3 collection step
+    // 50.85 -> 50.4 us; same process order, alternating).  Smaller launches keep one wavefront per workgroup, spread
+    // over as many CUs as there are wavefronts.  HEXVEC_QPB_WPG = 1..4 forces one form (A/B experiments).
+    static const int wpg_env = [] { const char *ev = getenv("HEXVEC_QPB_WPG"); return ev ? atoi(ev) : 0; }();
+    const int wpg = wpg_env >= 1 ? (wpg_env > 4 ? 4 : wpg_env) : (blocks >= 1024 ? 4 : 1);
+    hipLaunchKernelGGL((qpb::k_qpb<N, ENC, MODE>), dim3((blocks + wpg - 1) / wpg), dim3(64 * wpg), 0, st, a);
     return hipGetLastError();
 }
 template <int N, int ENC> static hipError_t qpb_launch_mode(int mode, const KArgs &a, hipStream_t st)
