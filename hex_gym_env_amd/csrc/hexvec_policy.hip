@@ -282,8 +282,16 @@ __device__ unsigned long long g_pol_stamps[8192][10];
         if (lane == 0 && tile < 8192) g_pol_stamps[tile][i] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     } while (0)
+// (k_mlp64_mfma2: row 2 * tile + wavefront)
+#define POL_MARK2(i)                                                                                       \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (lane == 0 && 2 * tile + w < 8192) g_pol_stamps[2 * tile + w][i] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    } while (0)
 #else
 #define POL_MARK(i) do { } while (0)
+#define POL_MARK2(i) do { } while (0)
 #endif
 
 constexpr int MF_WAVES = 4; // wavefronts (= tiles of 32 boards) per workgroup; they share nothing
@@ -501,7 +509,25 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     const int tile = (int)blockIdx.x;
     if (a.ntiles && tile >= 2 * *a.ntiles) return; // (workgroup-uniform, like every exit below)
     const int cells = a.ms.cells, T1 = a.ms.T1;
+    POL_MARK2(0);
 
+    // A tile of whole, ungrouped rows: its observation and mask rows are requested FIRST (loads return in order, and the
+    // rows are what the first barrier waits for: behind 65 weight records they arrive later), up to 4 dwords of each
+    // array per thread (boards up to 8x8; larger ones copy in a loop below)
+    const bool whole = !a.order && tile * 32 + 32 <= a.rows && (((uintptr_t)a.obs | (uintptr_t)a.legal) & 3) == 0;
+    const bool whole_pre = whole && cells <= 64;
+    u32 row_o[4], row_l[4];
+    if (whole_pre) {
+        const u32 *so = reinterpret_cast<const u32 *>(a.obs + (size_t)tile * 32 * cells);
+        const u32 *sl = reinterpret_cast<const u32 *>(a.legal + (size_t)tile * 32 * cells);
+        const int nd = 8 * cells;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = min((int)threadIdx.x + 128 * k, nd - 1);
+            row_o[k] = so[i];
+            row_l[k] = sl[i];
+        }
+    }
     // this wavefront's records: layer 2 (33) and the first 16 steps of layer 1, requested before the boards' rows --
     // with ONE network before anything else is known about the tile
     const bool one_net = !(a.slot && a.n_policies > 1);
@@ -515,8 +541,11 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
 #pragma unroll
         for (int s = 0; s < 33; ++s) w2r[s] = wl[a.ms.o_w2 + (size_t)(s * 2 + w) * 64];
     };
+    // (up to 32 k steps -- boards up to 7x7 -- the whole of layer 1 is requested here: no record is waited for inside it)
+    const bool l1_whole = T1 <= 32;
     if (one_net) {
         wload1(wa, 0);
+        if (l1_whole) wload1(wb, 16);
         wload2();
     }
     const int pos = tile * 32 + b;
@@ -531,6 +560,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         const int r0 = __builtin_amdgcn_readlane(r, (int)__ffsll((long long)vmask) - 1);
         wl += (size_t)rfl(policy_key(a, r0)) * (size_t)a.ms.stride;
         wload1(wa, 0);
+        if (l1_whole) wload1(wb, 16);
         wload2();
     }
 
@@ -543,8 +573,17 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     float *red_v = hB + 64 * 32;
     int *red_i = reinterpret_cast<int *>(red_v + 32);
     int *red_b = red_i + 32;
-    const bool whole = !a.order && tile * 32 + 32 <= a.rows && (((uintptr_t)a.obs | (uintptr_t)a.legal) & 3) == 0;
-    if (whole) {
+    if (whole_pre) {
+        const int nd = 8 * cells; // <= 512 dwords per array
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = (int)threadIdx.x + 128 * k;
+            if (i < nd) {
+                reinterpret_cast<u32 *>(obs_w)[i] = row_o[k];
+                reinterpret_cast<u32 *>(legal_w)[i] = row_l[k];
+            }
+        }
+    } else if (whole) {
         const u32 *so = reinterpret_cast<const u32 *>(a.obs + (size_t)tile * 32 * cells);
         const u32 *sl = reinterpret_cast<const u32 *>(a.legal + (size_t)tile * 32 * cells);
         const int nd = 8 * cells;
@@ -576,12 +615,12 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         }
     }
     __syncthreads();
+    POL_MARK2(1); // rows in LDS
 
     // layer 1, neuron tile w
     f32x16 h = {0};
     {
-        auto chunk = [&](const float(&wr)[16], int t0) {
-            float x[16];
+        auto inputs = [&](float(&x)[16], int t0) { // the B operands of k steps t0 .. t0 + 15: two inputs of this lane's board each
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int t = t0 + i;
@@ -589,10 +628,27 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
                 const float o = (float)(int)obs_w[b * cells + min(in, cells - 1)];
                 x[i] = t < T1 ? (in < cells ? o : (in == cells ? 1.0f : 0.0f)) : 0.0f;
             }
+        };
+        auto chunk = [&](const float(&wr)[16], int t0) {
+            float x[16];
+            inputs(x, t0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x[i], h, 0, 0, 0);
         };
+        if (l1_whole) {
+            // both halves' inputs are read before the first MFMA issues, the k steps past T1 (zero inputs) are not run
+            float xa[16], xb[16];
+            inputs(xa, 0);
+            inputs(xb, 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < T1) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], xa[i], h, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (16 + i < T1) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i], xb[i], h, 0, 0, 0);
+        } else
         for (int t0 = 0; t0 < T1; t0 += 32) {
             wload1(wb, t0 + 16);
             chunk(wa, t0);
@@ -600,6 +656,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
             chunk(wb, t0 + 16);
         }
     }
+    POL_MARK2(2); // layer 1 MFMAs
 #pragma unroll
     for (int v = 0; v < 16; ++v) hA[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(h[v]);
     // the first of this wavefront's output tiles: requested before layer 2 runs
@@ -608,6 +665,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
 #pragma unroll
     for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)(w * 33 + s) * 64];
     __syncthreads();
+    POL_MARK2(3); // tanh 1 + barrier
     // layer 2, neuron tile w: all 64 activations of layer 1 come back from LDS in k-step order
     const float one = half == 0 ? 1.0f : 0.0f;
     f32x16 g = {0};
@@ -619,9 +677,11 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
 #pragma unroll
         for (int s = 0; s < 33; ++s) g = __builtin_amdgcn_mfma_f32_32x32x2f32(w2r[s], x[s], g, 0, 0, 0);
     }
+    POL_MARK2(4); // layer 2 MFMAs
 #pragma unroll
     for (int v = 0; v < 16; ++v) hB[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(g[v]);
     __syncthreads();
+    POL_MARK2(5); // tanh 2 + barrier
     float xs[33];
 #pragma unroll
     for (int s = 0; s < 33; ++s) xs[s] = s < 32 ? hB[mfma_in(s, half) * 32 + b] : one;
@@ -682,6 +742,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         pk.besti = take ? oi : pk.besti;
         pk.bad = pk.bad || obad != 0;
     }
+    POL_MARK2(6); // layer 3 + epilogue
     if (w == 1 && half == 0) {
         red_v[b] = pk.best;
         red_i[b] = pk.besti;
@@ -701,6 +762,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         const u64 dm = __ballot(degenerate);
         if (dm && a.bad_rows && lane == 0) atomicAdd(a.bad_rows, (unsigned long long)__popcll(dm));
     }
+    POL_MARK2(7);
 }
 
 // row-major Linear weights ([out][in], torch's layout) -> the packed form of one network

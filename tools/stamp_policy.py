@@ -30,6 +30,7 @@ import torch
 from hex_gym_env_amd import _lib
 from hex_gym_env_amd.vec_selfplay import MlpActorPolicy, mlp_actions
 
+SPLIT = os.environ.get("HEXVEC_MLP_NOSPLIT") is None   # stamps of k_mlp64_mfma2 (two wavefronts per tile): rows 2 * tile + w
 names = ["rows requested + written to LDS", "layer 1 MFMAs", "tanh 1", "layer 2 MFMAs", "tanh 2", "layer 3 MFMAs + epilogues", "combine + store"]
 for n, E in ((7, 32), (7, 32768), (7, 262144), (11, 32), (11, 65536), (11, 262144)):
     Cc = n * n
@@ -41,6 +42,8 @@ for n, E in ((7, 32), (7, 32768), (7, 262144), (11, 32), (11, 65536), (11, 26214
         mlp_actions(pol.packed(), Cc, 64, 64, obs, legal, rng=(st, 1, 0, False))
     torch.cuda.synchronize()
     nt = min(E // 32, 8192)
+    if SPLIT and 2 * (E // 32) * 2 <= 3 * 1024:
+        nt = min(2 * (E // 32), 8192)
     buf = np.zeros((nt, 10), np.uint64)
     assert _lib.lib().hexvec_debug_policy_stamps(buf.ctypes.data_as(C.c_void_p), nt) == 0
     d = np.diff(buf[:, :8].astype(np.int64), axis=1).astype(np.float64)
