@@ -548,6 +548,19 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         if (l1_whole) wload1(wb, 16);
         wload2();
     }
+    // the first of this wavefront's output tiles: with one network requested in the opening burst too (its address
+    // arithmetic and issue then sit in the shadow of the rows' round trip, not between layer 1 and its barrier).
+    // (Measured and dropped: all records through buffer loads with scalar offsets -- 900 address instructions less per
+    // wavefront, and no faster: 47.3-47.4 us per collection step at config 3 with everything requested up front, 46.2 with
+    // the later layers requested after the first barrier, against 45.6-46.3 as it stands.  The kernel waits for round
+    // trips at this batch, not for its instruction stream.)
+    float w3p[33];
+    auto wload3 = [&]() {
+        const float *__restrict__ w3 = wl + a.ms.o_w3;
+#pragma unroll
+        for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)(w * 33 + s) * 64];
+    };
+    if (one_net) wload3();
     const int pos = tile * 32 + b;
     int r = a.order ? a.order[pos] : (pos < a.rows ? pos : -1);
     if (!a.order && r >= 0 && a.row_active && a.row_active[r] == 0) {
@@ -562,6 +575,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         wload1(wa, 0);
         if (l1_whole) wload1(wb, 16);
         wload2();
+        wload3();
     }
 
     // LDS: obs [32][cells] | legal [32][cells] | hA [64][32] floats | hB [64][32] floats | reduction 3 x [32]
@@ -659,11 +673,6 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     POL_MARK2(2); // layer 1 MFMAs
 #pragma unroll
     for (int v = 0; v < 16; ++v) hA[(w * 32 + mfma_row(v, half)) * 32 + b] = tanh_fast(h[v]);
-    // the first of this wavefront's output tiles: requested before layer 2 runs
-    float w3p[33];
-    const float *__restrict__ w3 = wl + a.ms.o_w3;
-#pragma unroll
-    for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)(w * 33 + s) * 64];
     __syncthreads();
     POL_MARK2(3); // tanh 1 + barrier
     // layer 2, neuron tile w: all 64 activations of layer 1 come back from LDS in k-step order
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
         }
         if (mt + 2 < a.ms.MT3) {
 #pragma unroll
-            for (int s = 0; s < 33; ++s) w3p[s] = w3[(size_t)((mt + 2) * 33 + s) * 64];
+            for (int s = 0; s < 33; ++s) w3p[s] = (wl + a.ms.o_w3)[(size_t)((mt + 2) * 33 + s) * 64];
         }
         if (a.logits_out) {
 #pragma unroll
