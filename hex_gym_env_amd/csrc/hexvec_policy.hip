@@ -512,21 +512,27 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     POL_MARK2(0);
 
     // A tile of whole, ungrouped rows: its observation and mask rows are requested FIRST (loads return in order, and the
-    // rows are what the first barrier waits for: behind 65 weight records they arrive later), up to 4 dwords of each
-    // array per thread (boards up to 8x8; larger ones copy in a loop below)
+    // rows are what the first barrier waits for: behind 65 weight records they arrive later), up to ROWK dwords of
+    // each array per thread (4: boards up to 8x8; larger ones copy in a loop below -- with 11, up to 13x13, the
+    // 13x13 / 16 384 launch stayed at 31.6 us: one wavefront per SIMD there, bound by its own 96-step layer 1)
+#ifndef HV_POL_ROWK
+#define HV_POL_ROWK 4
+#endif
+    constexpr int ROWK = HV_POL_ROWK;
     const bool whole = !a.order && tile * 32 + 32 <= a.rows && (((uintptr_t)a.obs | (uintptr_t)a.legal) & 3) == 0;
-    const bool whole_pre = whole && cells <= 64;
-    u32 row_o[4], row_l[4];
+    const bool whole_pre = whole && 8 * cells <= 128 * ROWK;
+    u32 row_o[ROWK], row_l[ROWK];
     if (whole_pre) {
         const u32 *so = reinterpret_cast<const u32 *>(a.obs + (size_t)tile * 32 * cells);
         const u32 *sl = reinterpret_cast<const u32 *>(a.legal + (size_t)tile * 32 * cells);
         const int nd = 8 * cells;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = min((int)threadIdx.x + 128 * k, nd - 1);
-            row_o[k] = so[i];
-            row_l[k] = sl[i];
-        }
+        for (int k = 0; k < ROWK; ++k)
+            if (128 * k < nd) { // (workgroup-uniform)
+                const int i = min((int)threadIdx.x + 128 * k, nd - 1);
+                row_o[k] = so[i];
+                row_l[k] = sl[i];
+            }
     }
     // this wavefront's records: layer 2 (33) and the first 16 steps of layer 1, requested before the boards' rows --
     // with ONE network before anything else is known about the tile
@@ -588,9 +594,9 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     int *red_i = reinterpret_cast<int *>(red_v + 32);
     int *red_b = red_i + 32;
     if (whole_pre) {
-        const int nd = 8 * cells; // <= 512 dwords per array
+        const int nd = 8 * cells;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < ROWK; ++k) {
             const int i = (int)threadIdx.x + 128 * k;
             if (i < nd) {
                 reinterpret_cast<u32 *>(obs_w)[i] = row_o[k];
