@@ -649,13 +649,6 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
                 x[i] = t < T1 ? (in < cells ? o : (in == cells ? 1.0f : 0.0f)) : 0.0f;
             }
         };
-        auto chunk = [&](const float(&wr)[16], int t0) {
-            float x[16];
-            inputs(x, t0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x[i], h, 0, 0, 0);
-        };
         if (l1_whole) {
             // both halves' inputs are read before the first MFMA issues, the k steps past T1 (zero inputs) are not run
             float xa[16], xb[16];
@@ -668,12 +661,24 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (16 + i < T1) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i], xb[i], h, 0, 0, 0);
-        } else
-        for (int t0 = 0; t0 < T1; t0 += 32) {
-            wload1(wb, t0 + 16);
-            chunk(wa, t0);
-            wload1(wa, t0 + 32);
-            chunk(wb, t0 + 16);
+        } else {
+            // (the k steps past T1 -- zero inputs -- are not run: 11 of 96 at 13x13.  Requesting every chunk's records two
+            // chunks ahead instead of one, three buffers in rotation, changed nothing: the records are not what layer 1
+            // waits for at the large boards, its 16 byte-reads-and-converts per chunk are.)
+            auto chunk_g = [&](const float(&wr)[16], int t0) {
+                float x[16];
+                inputs(x, t0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t0 + i < T1) h = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i], x[i], h, 0, 0, 0);
+            };
+            for (int t0 = 0; t0 < T1; t0 += 32) {
+                wload1(wb, t0 + 16);
+                chunk_g(wa, t0);
+                wload1(wa, t0 + 32);
+                if (t0 + 16 < T1) chunk_g(wb, t0 + 16);
+            }
         }
     }
     POL_MARK2(2); // layer 1 MFMAs
