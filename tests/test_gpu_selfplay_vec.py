@@ -433,6 +433,7 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["timed_reps"] >= 20 and d["warmup_internal_ms"] >= 100.0
+    assert d["reps_per_event"] >= 1 and d["timed_reps"] % d["reps_per_event"] == 0   # one HIP event per group of repetitions
     assert abs(d["wall_ms_per_step"] - d["ms_per_step"]) / d["ms_per_step"] < 0.5   # launch-bound at this size
     assert abs(r["obs_only_frac"] - r["frac"] * 121 / 251) < 1e-9 and r["kernel"].startswith("k_lpb") and d["host_stepped"]["kernel"].startswith("k_qpb")
     c = d["cpu_baseline"]
