@@ -302,7 +302,9 @@ __global__ __launch_bounds__(64 * MF_WAVES) __attribute__((amdgpu_waves_per_eu(2
     const int lane = (int)threadIdx.x & 63;
     const int wave = rfl((int)threadIdx.x >> 6);
     const int b = lane & 31, half = lane >> 5; // board of the tile; which input of a k pair / which rows of D
-    const int tile = (int)blockIdx.x * MF_WAVES + wave;
+    // (ungrouped launches: consecutive tiles per XCD, the board ranges the env kernels give an XCD -- see k_mlp64_mfma2)
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int tile = ((!a.order && (nwg & 7) == 0) ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg) * MF_WAVES + wave;
     if (a.ntiles && tile >= 2 * *a.ntiles) return; // (the grouping counts tiles of 64)
     const int cells = a.ms.cells, T1 = a.ms.T1;
 
@@ -506,7 +508,11 @@ __global__ __launch_bounds__(128) void k_mlp64_mfma2(MlpArgs a)
     const int lane = (int)threadIdx.x & 63;
     const int w = rfl((int)threadIdx.x >> 6);
     const int b = lane & 31, half = lane >> 5;
-    const int tile = (int)blockIdx.x;
+    // Ungrouped launches: consecutive tiles per XCD (workgroups go round-robin over the 8 XCDs), the same board ranges the
+    // env kernels give an XCD (hexvec_qpb.h) -- what the env launch before this one wrote and what the one behind it
+    // reads (observations, masks, actions) then stays in that XCD's L2.
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int tile = (!a.order && (nwg & 7) == 0) ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg;
     if (a.ntiles && tile >= 2 * *a.ntiles) return; // (workgroup-uniform, like every exit below)
     const int cells = a.ms.cells, T1 = a.ms.T1;
     POL_MARK2(0);
