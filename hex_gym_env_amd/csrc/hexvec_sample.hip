@@ -38,7 +38,11 @@ __global__ __launch_bounds__(256) void k_sample_masked(const float *logits, long
                                                        unsigned long long *bad_rows)
 {
     const int sub = (int)threadIdx.x & 15;
-    const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    // consecutive row ranges per XCD (workgroups go round-robin over the 8 XCDs): the board ranges the env kernels give
+    // an XCD, so the masks an env launch wrote and the actions the next one reads stay in that XCD's L2
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int wgr = (nwg & 7) == 0 ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg;
+    const int row = (int)((wgr * blockDim.x + threadIdx.x) >> 4);
     if (row >= rows) return; // a 16-lane row is all in or all out
     if (row_active && row_active[row] == 0) { // nobody asked for this board's action
         if (sub == 0) actions[row] = 0;
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(256) void k_pick_opponents(long long *slot, int whe
                                                         int pool_size, u32 seed_lo, u32 seed_hi, u32 salt,
                                                         const unsigned long long *state)
 {
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x; // (consecutive board ranges per XCD, as in k_sample_masked)
+    const int e = (int)(((nwg & 7) == 0 ? (wg & 7) * (nwg >> 3) + (wg >> 3) : wg) * blockDim.x + threadIdx.x);
     if (e >= rows) return;
     // when 3 = points 0 and 1 of the step in one launch, 4 = points 1 and 2: a board qualifies at one point at most
     // (0 needs pending == 0, 1 pending == 2; 2 a BLACK agent, 1 after the replies a WHITE one); the second point
